@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- AES-128 block witnesses/s and achieved HBM GB/s on N MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N>1 is launched by torch.distributed.run, one rank per GPU.
+A "step" is one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: one aesw_encrypt_witness_device launch over
+BASELINE.json configs[1] -- 2^16 blocks, one shared key, 1 MI355X -- per rank
+(weak scaling: every rank generates its own 2^16-block shard, no collective on
+the data path; see halo2-aes_amd/sharding.py).  Rank 0 prints ONE JSON line.
+
+roofline.achieved = algorithmic bytes per launch (3040 B/block shared key,
+3992 B/block per-block keys: SURVEY.md 8(d)) / average launch
+duration measured here with HIP events on the launch stream.
+cpu_baseline = the CPU oracle (a port of the reference's value path, NOT the
+reference: Rust + halo2 cannot be built here) timed on this box's host cores on
+a bounded sample, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+BYTES_SHARED = 3040     # 3024 live cells written + 16 B plaintext read per block
+BYTES_PBK = 3992        # + 936 key-schedule cells + 16 B key read per block
+SEED = 0xA35128
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--layout", choices=["packed", "dense"], default="packed")
+    ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
+                    help="c1 = 2^16 blocks shared key (BASELINE configs[1]); c2 = 2^20 blocks per-block keys")
+    ap.add_argument("--log2-blocks", type=int, default=None, help="override the batch size (per rank)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of a hipGraph")
+    ap.add_argument("--option", action="append", default=[], help="name=value passed to aesw_set_option")
+    return ap.parse_args()
+
+
+class Runner:
+    """One workload: inputs resident in HBM, a ring of output buffer sets larger
+    than the 256 MiB Infinity Cache so consecutive steps do not rewrite cached lines."""
+
+    def __init__(self, pkg, ctx, torch, n, per_block_keys, layout, key_slab, seed):
+        self.pkg, self.ctx, self.torch, self.n = pkg, ctx, torch, n
+        self.pbk, self.layout, self.key_slab = per_block_keys, layout, key_slab
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g).cuda()
+        self.keys = torch.randint(0, 256, (n, 16) if per_block_keys else (16,), dtype=torch.uint8, generator=g).cuda()
+        per_set = sum(pkg.column_stride(layout, c) for c in range(3)) * n
+        if key_slab:
+            per_set += (96 + sum(pkg.key_column_stride(layout, c) for c in range(3))) * n
+        self.out_bytes_per_step = per_set
+        self.nsets = max(2, min(8, -(-(640 << 20) // per_set)))
+        self.sets = [ctx.alloc_witness(n, layout, want_ct=False, key_slab=key_slab, n_keys=n) for _ in range(self.nsets)]
+        self.lib = pkg.load_library()
+        self.h = ctx._h
+        self._ks = [pkg.api.KeySlab(*[t.data_ptr() for t in s.key[:4]]) if key_slab else None for s in self.sets]
+        self.bytes_per_block = BYTES_PBK if (per_block_keys and key_slab) else BYTES_SHARED
+
+    def launch(self, i, stream):
+        s = self.sets[i % self.nsets]
+        ks = self._ks[i % self.nsets]
+        rc = self.lib.aesw_encrypt_witness_device(
+            self.h, self.pt.data_ptr(), self.keys.data_ptr(), 1 if self.pbk else 0, self.n, self.layout,
+            s.x.data_ptr(), s.y.data_ptr(), s.z.data_ptr(), None, C.byref(ks) if ks is not None else None, stream)
+        if rc:
+            raise RuntimeError("aesw_encrypt_witness_device rc=%d %s" % (rc, self.lib.aesw_last_error(self.h).decode()))
+
+    def run(self, steps, warmup, use_graph, barrier=None):
+        """Returns (wall seconds for `steps` steps, mean launch duration in ms from HIP events)."""
+        torch = self.torch
+        stream = torch.cuda.current_stream()
+        sp = C.c_void_p(stream.cuda_stream)
+        for i in range(warmup):
+            self.launch(i, sp)
+        torch.cuda.synchronize()
+        graph = None
+        if use_graph:
+            try:
+                # one hipGraph holding all K launches: no per-step host work in the timed region
+                cap = torch.cuda.Stream()
+                cap.wait_stream(stream)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cap):
+                    csp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    for i in range(steps):
+                        self.launch(i, csp)
+                graph.replay()  # untimed: instantiate / upload
+                torch.cuda.synchronize()
+            except Exception as e:  # pragma: no cover - depends on the runtime
+                print("bench: hipGraph capture unavailable (%s); launching from the host" % e, file=sys.stderr)
+                graph = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(steps):
+                self.launch(i, sp)
+        e1.record()
+        torch.cuda.synchronize()
+        if barrier:
+            barrier()
+        t1 = time.perf_counter()
+        return t1 - t0, e0.elapsed_time(e1) / steps, graph is not None
+
+
+def cpu_baseline(n_target_seconds=12.0):
+    """The CPU oracle on this host's cores: 1 thread (the reference synthesizes
+    single-threaded) on a bounded sample of the same workload shape."""
+    import numpy as np
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    rng = np.random.default_rng(SEED + 1)
+    probe = 2048
+    pt = rng.integers(0, 256, (probe, 16), dtype=np.uint8)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    t0 = time.perf_counter()
+    orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=1)
+    rate = probe / (time.perf_counter() - t0)
+    n = int(max(4096, min(1 << 18, rate * n_target_seconds)))
+    pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    t0 = time.perf_counter()
+    orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=1)
+    dt1 = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=cores)
+    dtn = time.perf_counter() - t0
+    return {
+        "value": n / dt1, "unit": "blocks/s", "cores": 1, "kind": "port",
+        "sample": "%d blocks, shared key, packed layout, oracle/aesw_oracle.c single thread (%.1f s)" % (n, dt1),
+        "all_cores": {"value": n / dtn, "cores": cores},
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        print("bench: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, a.gpus), file=sys.stderr)
+    import torch
+    import __graft_entry__ as ge
+    ge.build()
+    pkg = ge.load_package()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev)
+    ctx = pkg.Context(dev)
+    for opt in a.option:
+        k, v = opt.split("=")
+        ctx.set_option(k, int(v))
+    layout = pkg.LAYOUT_PACKED if a.layout == "packed" else pkg.LAYOUT_DENSE
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    if a.workload == "c1":
+        n = 1 << (a.log2_blocks or 16)
+        runner = Runner(pkg, ctx, torch, n, False, layout, False, SEED + 1 + rank)
+        wl = "2^%d blocks, one shared key, %s advice columns" % (a.log2_blocks or 16, a.layout)
+    else:
+        n = 1 << (a.log2_blocks or 20)
+        runner = Runner(pkg, ctx, torch, n, True, layout, True, SEED + 2 + rank)
+        wl = "2^%d blocks, per-block keys (+ key-schedule witness), %s advice columns" % (a.log2_blocks or 20, a.layout)
+    wall, ms_launch, graphed = runner.run(a.steps, a.warmup, not a.no_graph, barrier)
+    if dist is not None:
+        t = torch.tensor([wall, ms_launch], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, ms_launch = float(t[0]), float(t[1])
+    total_blocks = n * world * a.steps
+    value = total_blocks / wall
+    achieved = runner.bytes_per_block * n / (ms_launch * 1e-3) / 1e9
+
+    traffic = None
+    tp = ROOT / "profiles" / "traffic.json"
+    if tp.exists():
+        try:
+            tj = json.loads(tp.read_text())
+            traffic = tj.get("%s_%s" % (a.workload, a.layout))
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "AES-128 block witnesses/sec", "value": value, "unit": "blocks/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall * 1e3 / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": wl, "blocks_per_gpu": n, "layout": a.layout, "sharding": "blocks by rank, no collective",
+                   "launch": "hipGraph of %d launches" % a.steps if graphed else "host launches",
+                   "output_ring_sets": runner.nsets},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "aesw::encrypt_kernel", "launch_ms": ms_launch,
+                     "algorithmic_bytes_per_block": runner.bytes_per_block},
+        "achieved_hbm_GBps_all_gpus": achieved * world,
+    }
+
+    extras = {}
+    if rank == 0 and world == 1 and not a.no_extras:
+        # secondary measurements (not `value`): the other layout and BASELINE configs[2]
+        del runner
+        torch.cuda.empty_cache()
+        for name, nn, pbk, lay in (("c1_dense", 1 << 16, False, pkg.LAYOUT_DENSE),
+                                   ("c1_packed_2p20", 1 << 20, False, pkg.LAYOUT_PACKED),
+                                   ("c2_packed", 1 << 20, True, pkg.LAYOUT_PACKED),
+                                   ("c2_dense", 1 << 20, True, pkg.LAYOUT_DENSE)):
+            try:
+                r = Runner(pkg, ctx, torch, nn, pbk, lay, pbk, SEED + 7)
+                steps = 50 if nn <= (1 << 16) else 12
+                w, ms, _ = r.run(steps, 3, not a.no_graph)
+                extras[name] = {"blocks": nn, "blocks_per_s": nn * steps / w, "launch_ms": ms,
+                                "achieved_GBps": r.bytes_per_block * nn / (ms * 1e-3) / 1e9,
+                                "frac": r.bytes_per_block * nn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                "written_GBps": r.out_bytes_per_step / (ms * 1e-3) / 1e9}
+                del r
+                torch.cuda.empty_cache()
+            except Exception as e:  # keep the headline even if an extra fails
+                extras[name] = {"error": str(e)}
+        line["extra"] = extras
+    if rank == 0 and world == 1 and not a.no_cpu:
+        line["cpu_baseline"] = cpu_baseline()
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

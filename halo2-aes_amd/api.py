@@ -1,0 +1,350 @@
+"""ctypes binding of include/aesw.h plus a thin tensor-level wrapper.
+
+PyTorch is plumbing only: device memory (``torch.empty(..., device="cuda")``),
+the current HIP stream and ``torch.distributed``.  All compute happens in
+``libaesw.so`` (hand-written gfx950 kernels) through the C ABI; if the library
+is missing or no gfx950 device is usable this module raises -- there is no
+fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+from pathlib import Path
+
+import numpy as np
+
+from . import constants as K
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libaesw.so"
+
+STATUS = {
+    0: "AESW_OK", 1: "AESW_ERR_INVALID_ARG", 2: "AESW_ERR_NO_DEVICE", 3: "AESW_ERR_HIP", 4: "AESW_ERR_NOMEM",
+    5: "AESW_ERR_CAPACITY", 6: "AESW_ERR_NO_KEY", 7: "AESW_ERR_MISMATCH", 8: "AESW_ERR_UNSATISFIED",
+}
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_NO_KEY, ERR_MISMATCH = range(8)
+
+
+class AeswError(RuntimeError):
+    def __init__(self, status: int, detail: str = ""):
+        self.status = status
+        msg = "%s (%d): %s" % (STATUS.get(status, "?"), status, _strerror(status))
+        if detail:
+            msg += " -- " + detail
+        super().__init__(msg)
+
+
+class KeySlab(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("kx", C.c_void_p), ("ky", C.c_void_p), ("kz", C.c_void_p)]
+
+
+# every symbol include/aesw.h declares: (restype, argtypes)
+_P, _I, _U64, _U32, _I64 = C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_int64
+SYMBOLS = {
+    "aesw_version": (_I, []),
+    "aesw_strerror": (C.c_char_p, [_I]),
+    "aesw_last_error": (C.c_char_p, [_P]),
+    "aesw_device_count": (_I, [C.POINTER(_I)]),
+    "aesw_create": (_I, [C.POINTER(_P), _I, _P, _P, _P]),
+    "aesw_destroy": (None, [_P]),
+    "aesw_device": (_I, [_P]),
+    "aesw_column_stride": (_U32, [_I, _I]),
+    "aesw_key_column_stride": (_U32, [_I, _I]),
+    "aesw_packed_index": (_I, [_I, _P]),
+    "aesw_key_packed_index": (_I, [_I, _P]),
+    "aesw_block_placement": (_I, [_U32, _U32, _U64, C.POINTER(_U32), C.POINTER(_U64)]),
+    "aesw_block_capacity": (_U64, [_U32, _U32]),
+    "aesw_encrypt_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P]),
+    "aesw_key_schedule_witness_device": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P, _P]),
+    "aesw_lookup_table_device": (_I, [_P, _P, _P, _P, _P, _P]),
+    "aesw_expand_fr_device": (_I, [_P, _P, _U64, _P, _P]),
+    "aesw_encrypt_witness": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab)]),
+    "aesw_key_schedule_witness": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P]),
+    "aesw_lookup_table": (_I, [_P, _P, _P, _P, _P]),
+    "aesw_set_option": (_I, [_P, C.c_char_p, _I64]),
+    "aesw_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I64)]),
+    "aesw_uses_xtime_path": (_I, [_P]),
+}
+
+_lib = None
+
+
+def load_library(path: Path | None = None) -> C.CDLL:
+    """Load libaesw.so (in-tree).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise FileNotFoundError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback implementation." % p)
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _strerror(status: int) -> str:
+    try:
+        return load_library().aesw_strerror(status).decode()
+    except Exception:  # library not built yet
+        return ""
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- pure-host geometry -----------------------------------------------------------
+
+def column_stride(layout: int, col: int) -> int:
+    return int(load_library().aesw_column_stride(layout, col))
+
+
+def key_column_stride(layout: int, col: int) -> int:
+    return int(load_library().aesw_key_column_stride(layout, col))
+
+
+def packed_index(col: int) -> np.ndarray:
+    idx = np.zeros(K.AES_ROWS, dtype=np.int32)
+    rc = load_library().aesw_packed_index(col, _np_ptr(idx))
+    if rc:
+        raise AeswError(rc)
+    return idx
+
+
+def key_packed_index(col: int) -> np.ndarray:
+    idx = np.zeros(K.KEY_ROWS, dtype=np.int32)
+    rc = load_library().aesw_key_packed_index(col, _np_ptr(idx))
+    if rc:
+        raise AeswError(rc)
+    return idx
+
+
+def block_placement(k: int, n_sets: int, b: int):
+    """(set, first row) of the b-th encrypt() call; raises AeswError(CAPACITY) where the reference panics."""
+    s, r = C.c_uint32(), C.c_uint64()
+    rc = load_library().aesw_block_placement(k, n_sets, b, C.byref(s), C.byref(r))
+    if rc:
+        raise AeswError(rc)
+    return int(s.value), int(r.value)
+
+
+def block_capacity(k: int, n_sets: int) -> int:
+    return int(load_library().aesw_block_capacity(k, n_sets))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    load_library().aesw_device_count(C.byref(n))
+    return int(n.value)
+
+
+Witness = namedtuple("Witness", "x y z ct key")
+KeyWitness = namedtuple("KeyWitness", "w kx ky kz rk")
+
+
+class Context:
+    """One aesw_ctx: a device plus the host's three byte tables."""
+
+    def __init__(self, device: int = 0, tables=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        sbox, mul2, mul3 = tables if tables is not None else K.reference_tables()
+        self._tables = tuple(np.ascontiguousarray(t, dtype=np.uint8) for t in (sbox, mul2, mul3))
+        for t in self._tables:
+            if t.shape != (256,):
+                raise ValueError("tables must be three uint8[256] arrays")
+        rc = self._lib.aesw_create(C.byref(self._h), device, *[_np_ptr(t) for t in self._tables])
+        if rc:
+            self._h = C.c_void_p()
+            raise AeswError(rc, "aesw_create(device=%d)" % device)
+        self.device = device
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.aesw_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int, what: str = ""):
+        if rc:
+            raise AeswError(rc, (what + " " + self._lib.aesw_last_error(self._h).decode()).strip())
+
+    # -- options
+    def set_option(self, name: str, value: int):
+        self._check(self._lib.aesw_set_option(self._h, name.encode(), int(value)), "set_option(%s)" % name)
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64()
+        self._check(self._lib.aesw_get_option(self._h, name.encode(), C.byref(v)), "get_option(%s)" % name)
+        return int(v.value)
+
+    @property
+    def uses_xtime_path(self) -> bool:
+        return bool(self._lib.aesw_uses_xtime_path(self._h))
+
+    # -- tensor plumbing
+    def _torch(self):
+        import torch
+        return torch
+
+    def _dev(self):
+        return self._torch().device("cuda", self.device)
+
+    def _stream(self):
+        return C.c_void_p(self._torch().cuda.current_stream(self.device).cuda_stream)
+
+    def _u8(self, t, what):
+        torch = self._torch()
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.uint8 or not t.is_cuda or t.device.index != self.device:
+            raise TypeError("%s must be a uint8 tensor on cuda:%d" % (what, self.device))
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % what)
+        return t
+
+    def alloc_witness(self, n: int, layout: int = K.LAYOUT_PACKED, want_ct: bool = False, key_slab: bool = False,
+                      n_keys: int | None = None):
+        torch = self._torch()
+        dev = self._dev()
+        cols = [torch.empty(n * column_stride(layout, c), dtype=torch.uint8, device=dev) for c in range(3)]
+        ct = torch.empty((n, 16), dtype=torch.uint8, device=dev) if want_ct else None
+        key = None
+        if key_slab:
+            m = n if n_keys is None else n_keys
+            key = KeyWitness(torch.empty(m * K.WORDS_ROWS, dtype=torch.uint8, device=dev),
+                             *[torch.empty(m * key_column_stride(layout, c), dtype=torch.uint8, device=dev)
+                               for c in range(3)], None)
+        return Witness(cols[0], cols[1], cols[2], ct, key)
+
+    # -- device entry points
+    def encrypt_witness(self, pt, keys, layout: int = K.LAYOUT_PACKED, out: Witness | None = None,
+                        want_ct: bool = False, key_slab: bool = False) -> Witness:
+        """Batched FixedAes128Config::encrypt witness (src/aes128.rs:154-265).
+
+        pt: uint8[n,16] on the device.  keys: uint8[16] (shared key, the
+        reference's schedule_key once + encrypt n times) or uint8[n,16]
+        (per-block keys).  Asynchronous on torch's current stream.
+        """
+        pt = self._u8(pt, "pt")
+        keys = self._u8(keys, "keys")
+        if pt.dim() != 2 or pt.shape[1] != 16:
+            raise ValueError("pt must be [n,16]")
+        n = pt.shape[0]
+        if keys.numel() == 16 and keys.dim() == 1:
+            pbk = 0
+        elif keys.dim() == 2 and tuple(keys.shape) == (n, 16):
+            pbk = 1
+        else:
+            raise ValueError("keys must be [16] (shared) or [n,16] (per block)")
+        if out is None:
+            out = self.alloc_witness(n, layout, want_ct, key_slab, n_keys=n if pbk else 1)
+        for c, name in enumerate("xyz"):
+            self._u8(out[c], name)
+            if out[c].numel() < n * column_stride(layout, c):
+                raise ValueError("column %s too small" % name)
+        ks = None
+        if out.key is not None:
+            ks = KeySlab(*[t.data_ptr() if t is not None else None for t in out.key[:4]])
+        rc = self._lib.aesw_encrypt_witness_device(
+            self._h, pt.data_ptr(), keys.data_ptr(), pbk, n, layout, out.x.data_ptr(), out.y.data_ptr(),
+            out.z.data_ptr(), out.ct.data_ptr() if out.ct is not None else None,
+            C.byref(ks) if ks is not None else None, self._stream())
+        self._check(rc, "aesw_encrypt_witness_device")
+        return out
+
+    def key_schedule_witness(self, keys, layout: int = K.LAYOUT_PACKED, want_rk: bool = True) -> KeyWitness:
+        """Aes128KeyScheduleConfig::schedule_keys witness for n keys (src/key_schedule.rs:80-224)."""
+        torch = self._torch()
+        keys = self._u8(keys, "keys")
+        if keys.dim() == 1:
+            keys = keys.reshape(1, 16)
+        if keys.dim() != 2 or keys.shape[1] != 16:
+            raise ValueError("keys must be [n,16]")
+        n = keys.shape[0]
+        dev = self._dev()
+        w = torch.empty(n * K.WORDS_ROWS, dtype=torch.uint8, device=dev)
+        kx, ky, kz = [torch.empty(n * key_column_stride(layout, c), dtype=torch.uint8, device=dev) for c in range(3)]
+        rk = torch.empty((n, 176), dtype=torch.uint8, device=dev) if want_rk else None
+        rc = self._lib.aesw_key_schedule_witness_device(
+            self._h, keys.data_ptr(), n, layout, w.data_ptr(), kx.data_ptr(), ky.data_ptr(), kz.data_ptr(),
+            rk.data_ptr() if rk is not None else None, self._stream())
+        self._check(rc, "aesw_key_schedule_witness_device")
+        return KeyWitness(w, kx, ky, kz, rk)
+
+    def lookup_table(self):
+        """load_enc_full_table (src/table.rs:18-192): four uint8[66561] columns on the device."""
+        torch = self._torch()
+        t = torch.empty((4, K.TABLE_ROWS), dtype=torch.uint8, device=self._dev())
+        rc = self._lib.aesw_lookup_table_device(self._h, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                                t[3].data_ptr(), self._stream())
+        self._check(rc, "aesw_lookup_table_device")
+        return t
+
+    def expand_fr(self, cells, out=None):
+        """uint8 cells -> [n,32] uint8 bn256::Fr Montgomery cells (Fp::from(u64), src/utils.rs:23)."""
+        torch = self._torch()
+        cells = self._u8(cells, "cells")
+        n = cells.numel()
+        if out is None:
+            out = torch.empty((n, 32), dtype=torch.uint8, device=self._dev())
+        rc = self._lib.aesw_expand_fr_device(self._h, cells.data_ptr(), n, out.data_ptr(), self._stream())
+        self._check(rc, "aesw_expand_fr_device")
+        return out
+
+    # -- host entry points (numpy in, numpy out)
+    def encrypt_witness_host(self, pt: np.ndarray, keys: np.ndarray, layout: int = K.LAYOUT_PACKED,
+                             want_ct: bool = False, key_slab: bool = False):
+        pt = np.ascontiguousarray(pt, dtype=np.uint8).reshape(-1, 16)
+        keys = np.ascontiguousarray(keys, dtype=np.uint8)
+        n = pt.shape[0]
+        pbk = 0 if keys.size == 16 else 1
+        if pbk and keys.size != n * 16:
+            raise ValueError("keys must hold 16 or n*16 bytes")
+        cols = [np.empty(n * column_stride(layout, c), dtype=np.uint8) for c in range(3)]
+        ct = np.empty((n, 16), dtype=np.uint8) if want_ct else None
+        key = ks = None
+        if key_slab:
+            m = n if pbk else 1
+            key = KeyWitness(np.empty(m * K.WORDS_ROWS, np.uint8),
+                             *[np.empty(m * key_column_stride(layout, c), np.uint8) for c in range(3)], None)
+            ks = KeySlab(*[a.ctypes.data for a in key[:4]])
+        rc = self._lib.aesw_encrypt_witness(self._h, _np_ptr(pt), _np_ptr(keys), pbk, n, layout, *[_np_ptr(c) for c in cols],
+                                            _np_ptr(ct) if ct is not None else None, C.byref(ks) if ks is not None else None)
+        self._check(rc, "aesw_encrypt_witness")
+        return Witness(cols[0], cols[1], cols[2], ct, key)
+
+    def key_schedule_witness_host(self, keys: np.ndarray, layout: int = K.LAYOUT_PACKED) -> KeyWitness:
+        keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 16)
+        n = keys.shape[0]
+        w = np.empty(n * K.WORDS_ROWS, np.uint8)
+        kx, ky, kz = [np.empty(n * key_column_stride(layout, c), np.uint8) for c in range(3)]
+        rk = np.empty((n, 176), np.uint8)
+        rc = self._lib.aesw_key_schedule_witness(self._h, _np_ptr(keys), n, layout, _np_ptr(w), _np_ptr(kx), _np_ptr(ky),
+                                                 _np_ptr(kz), _np_ptr(rk))
+        self._check(rc, "aesw_key_schedule_witness")
+        return KeyWitness(w, kx, ky, kz, rk)
+
+    def lookup_table_host(self) -> np.ndarray:
+        t = np.empty((4, K.TABLE_ROWS), dtype=np.uint8)
+        rc = self._lib.aesw_lookup_table(self._h, *[_np_ptr(t[i]) for i in range(4)])
+        self._check(rc, "aesw_lookup_table")
+        return t

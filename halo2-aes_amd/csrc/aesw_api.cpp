@@ -1,0 +1,515 @@
+// aesw_api.cpp -- the C ABI of include/aesw.h on top of the gfx950 kernels.
+// Host code only (compiled by hipcc for the HIP runtime API).  There is no CPU
+// compute path: without a usable device every computing entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/aesw.h"
+#include "aesw_internal.h"
+#include "aesw_layout.h"
+
+using namespace aesw;
+
+struct aesw_ctx {
+    int device = -1;
+    uint8_t *d_tables = nullptr;  // 768 B
+    uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
+    bool xt = false;
+    int waves_shared = 4;  // waves per group, shared-key kernel
+    int waves_pbk = 2;     // per-block-key and key kernels
+    bool nt = false;
+    int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
+    std::string last_error;
+    hipStream_t s_compute = nullptr, s_copy = nullptr;
+};
+
+namespace {
+
+int fail_hip(aesw_ctx *ctx, hipError_t e, const char *what) {
+    if (ctx) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        ctx->last_error = buf;
+    }
+    return e == hipErrorOutOfMemory ? AESW_ERR_NOMEM : AESW_ERR_HIP;
+}
+
+#define HIP_TRY(ctx, expr)                                  \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+bool valid_layout(int l) { return l == AESW_LAYOUT_DENSE || l == AESW_LAYOUT_PACKED; }
+
+uint8_t xtime(uint8_t a) { return (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0)); }
+
+// ---- bn256::Fr Montgomery table: v -> v * 2^256 mod r, 32 B little-endian ----
+// r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+// (halo2curves 0.6.1 bn256::Fr, Cargo.lock:779-781).
+struct U256 { uint64_t l[4]; };
+const U256 FR_MOD = {{0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull}};
+
+bool geq(const U256 &a, const U256 &b) {
+    for (int i = 3; i >= 0; --i) {
+        if (a.l[i] != b.l[i]) return a.l[i] > b.l[i];
+    }
+    return true;
+}
+// (a + b) mod r for a, b < r  (r < 2^254 so the sum fits in 256 bits)
+U256 add_mod(const U256 &a, const U256 &b) {
+    U256 s;
+    unsigned __int128 c = 0;
+    for (int i = 0; i < 4; ++i) {
+        c += (unsigned __int128)a.l[i] + b.l[i];
+        s.l[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (geq(s, FR_MOD)) {
+        unsigned __int128 br = 0;
+        for (int i = 0; i < 4; ++i) {
+            unsigned __int128 d = (unsigned __int128)s.l[i] - FR_MOD.l[i] - (uint64_t)br;
+            s.l[i] = (uint64_t)d;
+            br = (d >> 64) & 1;
+        }
+    }
+    return s;
+}
+void build_fr_lut(uint8_t out[256 * 32]) {
+    U256 R = {{1, 0, 0, 0}};
+    for (int i = 0; i < 256; ++i) R = add_mod(R, R);  // 2^256 mod r
+    U256 acc = {{0, 0, 0, 0}};
+    for (int v = 0; v < 256; ++v) {
+        std::memcpy(out + 32 * v, acc.l, 32);  // little-endian limbs
+        acc = add_mod(acc, R);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int aesw_version(void) { return AESW_VERSION; }
+
+const char *aesw_strerror(int status) {
+    switch (status) {
+    case AESW_OK: return "ok";
+    case AESW_ERR_INVALID_ARG: return "invalid argument";
+    case AESW_ERR_NO_DEVICE: return "no usable gfx950 device (this library has no CPU path)";
+    case AESW_ERR_HIP: return "HIP runtime error";
+    case AESW_ERR_NOMEM: return "out of memory";
+    case AESW_ERR_CAPACITY: return "AES calls too many. doesn't fit in the rows";
+    case AESW_ERR_NO_KEY: return "Keys should be scheduled";
+    case AESW_ERR_MISMATCH: return "host value disagrees with the device witness";
+    case AESW_ERR_UNSATISFIED: return "constraint system not satisfied";
+    default: return "unknown status";
+    }
+}
+
+const char *aesw_last_error(const aesw_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int aesw_device_count(int *count) {
+    if (!count) return AESW_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return n > 0 ? AESW_OK : AESW_ERR_NO_DEVICE;
+}
+
+int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8_t mul2[256],
+                const uint8_t mul3[256]) {
+    if (!out || !sbox || !mul2 || !mul3) return AESW_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return AESW_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return AESW_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return AESW_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return AESW_ERR_NO_DEVICE;  // code objects are gfx950 only
+    aesw_ctx *ctx = new (std::nothrow) aesw_ctx;
+    if (!ctx) return AESW_ERR_NOMEM;
+    ctx->device = device;
+    DeviceGuard g(device);
+    if (!g.ok) { delete ctx; return AESW_ERR_NO_DEVICE; }
+    uint8_t host[768];
+    std::memcpy(host, sbox, 256);
+    std::memcpy(host + 256, mul2, 256);
+    std::memcpy(host + 512, mul3, 256);
+    ctx->xt = true;
+    for (int i = 0; i < 256; ++i)
+        if (mul2[i] != xtime((uint8_t)i) || mul3[i] != (uint8_t)(xtime((uint8_t)i) ^ i)) ctx->xt = false;
+    uint8_t lut[256 * 32];
+    build_fr_lut(lut);
+    int rc = AESW_OK;
+    auto T = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == AESW_OK) rc = fail_hip(ctx, e, what);
+    };
+    T(hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), 768), "hipMalloc(tables)");
+    T(hipMalloc(reinterpret_cast<void **>(&ctx->d_fr_lut), sizeof lut), "hipMalloc(fr_lut)");
+    if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
+    if (rc == AESW_OK) T(hipMemcpy(ctx->d_fr_lut, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy(fr_lut)");
+    if (rc != AESW_OK) {
+        aesw_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return AESW_OK;
+}
+
+void aesw_destroy(aesw_ctx *ctx) {
+    if (!ctx) return;
+    {
+        DeviceGuard g(ctx->device);
+        if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
+        if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+        if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+        if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
+    }
+    delete ctx;
+}
+
+int aesw_device(const aesw_ctx *ctx) { return ctx ? ctx->device : -1; }
+int aesw_uses_xtime_path(const aesw_ctx *ctx) { return ctx && ctx->xt ? 1 : 0; }
+
+// ---- geometry ------------------------------------------------------------------
+
+uint32_t aesw_column_stride(int layout, int col) {
+    if (!valid_layout(layout) || col < 0 || col > 2) return 0;
+    if (layout == AESW_LAYOUT_DENSE) return AESW_AES_ROWS;
+    return col == 0 ? Geo<PACKED>::XS : col == 1 ? Geo<PACKED>::YS : Geo<PACKED>::ZS;
+}
+
+uint32_t aesw_key_column_stride(int layout, int col) {
+    if (!valid_layout(layout) || col < 0 || col > 2) return 0;
+    if (layout == AESW_LAYOUT_DENSE) return AESW_KEY_ROWS;
+    return col == 0 ? Geo<PACKED>::KXS : col == 1 ? Geo<PACKED>::KYS : Geo<PACKED>::KZS;
+}
+
+int aesw_packed_index(int col, int32_t idx[AESW_AES_ROWS]) {
+    if (col < 0 || col > 2 || !idx) return AESW_ERR_INVALID_ARG;
+    uint8_t mask[AES_ROWS];
+    encrypt_assigned_mask(col, mask);
+    int32_t n = 0;
+    for (int r = 0; r < AES_ROWS; ++r) idx[r] = mask[r] ? n++ : -1;
+    return AESW_OK;
+}
+
+int aesw_key_packed_index(int col, int32_t idx[AESW_KEY_ROWS]) {
+    if (col < 0 || col > 2 || !idx) return AESW_ERR_INVALID_ARG;
+    uint8_t mask[KEY_ROWS];
+    key_assigned_mask(col, mask);
+    int32_t n = 0;
+    for (int r = 0; r < KEY_ROWS; ++r) idx[r] = mask[r] ? n++ : -1;
+    return AESW_OK;
+}
+
+// FixedAes128Config::aes_callable, src/aes128.rs:303-325: set 0 is charged
+// KEY_SCHEDULE_ROWS (1760) of its 2^K rows, every set holds whole 1360-row
+// blocks.  Rows: set 0 starts behind the 400 rows the key schedule really uses.
+static uint64_t set_capacity(uint32_t k, uint32_t set) {
+    uint64_t max_row = (uint64_t)1 << k;
+    if (set == 0) {
+        if (max_row < AESW_KEY_SCHEDULE_ROWS) return 0;
+        max_row -= AESW_KEY_SCHEDULE_ROWS;
+    }
+    return max_row / AESW_AES_ROWS;
+}
+
+uint64_t aesw_block_capacity(uint32_t k, uint32_t n_sets) {
+    if (k > 40 || n_sets == 0) return 0;
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < n_sets; ++s) total += set_capacity(k, s);
+    return total;
+}
+
+int aesw_block_placement(uint32_t k, uint32_t n_sets, uint64_t b, uint32_t *set, uint64_t *row) {
+    if (k > 40 || n_sets == 0 || !set || !row) return AESW_ERR_INVALID_ARG;
+    uint64_t left = b;
+    for (uint32_t s = 0; s < n_sets; ++s) {
+        const uint64_t cap = set_capacity(k, s);
+        if (left < cap) {
+            *set = s;
+            *row = (s == 0 ? AESW_KEY_ROWS : 0) + left * AESW_AES_ROWS;
+            return AESW_OK;
+        }
+        left -= cap;
+    }
+    return AESW_ERR_CAPACITY;
+}
+
+// ---- options --------------------------------------------------------------------
+
+int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return AESW_ERR_INVALID_ARG;
+    if (!std::strcmp(name, "waves_shared")) { if (value < 1 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_shared = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "waves_pbk")) { if (value < 1 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_pbk = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "nt_stores")) { ctx->nt = value != 0; return AESW_OK; }
+    if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }
+    if (!std::strcmp(name, "chunk_blocks")) { if (value < 64) return AESW_ERR_INVALID_ARG; ctx->chunk_blocks = value; return AESW_OK; }
+    return AESW_ERR_INVALID_ARG;
+}
+
+int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return AESW_ERR_INVALID_ARG;
+    if (!std::strcmp(name, "waves_shared")) { *value = ctx->waves_shared; return AESW_OK; }
+    if (!std::strcmp(name, "waves_pbk")) { *value = ctx->waves_pbk; return AESW_OK; }
+    if (!std::strcmp(name, "nt_stores")) { *value = ctx->nt; return AESW_OK; }
+    if (!std::strcmp(name, "chunk_blocks")) { *value = ctx->chunk_blocks; return AESW_OK; }
+    return AESW_ERR_INVALID_ARG;
+}
+
+// ---- device-pointer entry points ------------------------------------------------
+
+int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys, int per_block_keys,
+                                uint64_t n, int layout, uint8_t *d_x, uint8_t *d_y, uint8_t *d_z, uint8_t *d_ct,
+                                const aesw_key_slab *ks, void *stream) {
+    if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;
+    if (n == 0) return AESW_OK;
+    if (!d_pt || !d_keys || !d_x || !d_y || !d_z) return AESW_ERR_INVALID_ARG;
+    if (!aligned16(d_x) || !aligned16(d_y) || !aligned16(d_z) || !aligned4(d_pt) || !aligned4(d_keys) ||
+        (d_ct && !aligned4(d_ct)))
+        return AESW_ERR_INVALID_ARG;
+    KeyOut ko{nullptr, nullptr, nullptr, nullptr};
+    if (ks) {
+        ko = KeyOut{ks->w, ks->kx, ks->ky, ks->kz};
+        if ((ko.w && !aligned16(ko.w)) || (ko.kx && !aligned16(ko.kx)) || (ko.ky && !aligned16(ko.ky)) ||
+            (ko.kz && !aligned16(ko.kz)))
+            return AESW_ERR_INVALID_ARG;
+    }
+    const bool kemit = ko.w || ko.kx || ko.ky || ko.kz;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!per_block_keys && kemit) {
+        // shared key: its schedule witness is one key slab
+        KeyParams kp{d_keys, ctx->d_tables, ko, nullptr, 1};
+        HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->nt, s));
+    }
+    EncParams p{d_pt, d_keys, ctx->d_tables, d_x, d_y, d_z, d_ct, per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n};
+    const int waves = per_block_keys ? ctx->waves_pbk : ctx->waves_shared;
+    HIP_TRY(ctx, launch_encrypt(p, layout, ctx->xt, per_block_keys != 0, per_block_keys && kemit, waves, ctx->nt, s));
+    return AESW_OK;
+}
+
+int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint64_t n, int layout, uint8_t *d_w,
+                                     uint8_t *d_kx, uint8_t *d_ky, uint8_t *d_kz, uint8_t *d_rk, void *stream) {
+    if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;
+    if (n == 0) return AESW_OK;
+    if (!d_keys || !aligned4(d_keys)) return AESW_ERR_INVALID_ARG;
+    if ((d_w && !aligned16(d_w)) || (d_kx && !aligned16(d_kx)) || (d_ky && !aligned16(d_ky)) ||
+        (d_kz && !aligned16(d_kz)) || (d_rk && !aligned16(d_rk)))
+        return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    KeyParams kp{d_keys, ctx->d_tables, KeyOut{d_w, d_kx, d_ky, d_kz}, d_rk, n};
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, ctx->waves_pbk, ctx->nt, reinterpret_cast<hipStream_t>(stream)));
+    return AESW_OK;
+}
+
+int aesw_lookup_table_device(aesw_ctx *ctx, uint8_t *d_t0, uint8_t *d_t1, uint8_t *d_t2, uint8_t *d_t3, void *stream) {
+    if (!ctx || !d_t0 || !d_t1 || !d_t2 || !d_t3) return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    HIP_TRY(ctx, launch_table(ctx->d_tables, d_t0, d_t1, d_t2, d_t3, reinterpret_cast<hipStream_t>(stream)));
+    return AESW_OK;
+}
+
+int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cells, uint8_t *d_fr, void *stream) {
+    if (!ctx) return AESW_ERR_INVALID_ARG;
+    if (n_cells == 0) return AESW_OK;
+    if (!d_cells || !d_fr || !aligned16(d_fr)) return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    HIP_TRY(ctx, launch_expand_fr(d_cells, n_cells, ctx->d_fr_lut, d_fr, reinterpret_cast<hipStream_t>(stream)));
+    return AESW_OK;
+}
+
+// ---- host-pointer entry points ----------------------------------------------------
+// Pipeline: blocks are cut into chunks; chunk i's kernel runs on s_compute
+// while chunk i-1's columns travel D2H on s_copy (two device buffer sets).
+
+namespace {
+
+struct DevBuf {
+    uint8_t *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void **>(&p), n ? n : 16); }
+};
+
+int ensure_streams(aesw_ctx *ctx) {
+    if (!ctx->s_compute) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_compute, hipStreamNonBlocking));
+    if (!ctx->s_copy) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_copy, hipStreamNonBlocking));
+    return AESW_OK;
+}
+
+// Pin the caller's output range for the duration of a call so D2H is truly async.
+struct Pinned {
+    void *p = nullptr;
+    bool ok = false;
+    void pin(void *ptr, size_t n) {
+        if (!ptr || !n) return;
+        ok = hipHostRegister(ptr, n, hipHostRegisterDefault) == hipSuccess;
+        if (ok) p = ptr; else (void)hipGetLastError();
+    }
+    ~Pinned() { if (ok) (void)hipHostUnregister(p); }
+};
+
+}  // namespace
+
+int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys, uint64_t n,
+                         int layout, uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct, const aesw_key_slab *ks) {
+    if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;
+    if (n == 0) return AESW_OK;
+    if (!pt || !keys || !x || !y || !z) return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    int rc = ensure_streams(ctx);
+    if (rc != AESW_OK) return rc;
+    const size_t sx = aesw_column_stride(layout, 0), sy = aesw_column_stride(layout, 1), sz = aesw_column_stride(layout, 2);
+    const size_t kxs = aesw_key_column_stride(layout, 0), kys = aesw_key_column_stride(layout, 1),
+                 kzs = aesw_key_column_stride(layout, 2);
+    const bool kemit = ks && (ks->w || ks->kx || ks->ky || ks->kz);
+    const bool pbk = per_block_keys != 0;
+    uint64_t chunk = (uint64_t)ctx->chunk_blocks;
+    if (chunk > n) chunk = n;
+    chunk = (chunk + 63) / 64 * 64;
+
+    DevBuf d_pt, d_keys, d_ct, dx[2], dy[2], dz[2], dw[2], dkx[2], dky[2], dkz[2];
+    HIP_TRY(ctx, d_pt.alloc(n * 16));
+    HIP_TRY(ctx, d_keys.alloc(pbk ? n * 16 : 16));
+    if (ct) HIP_TRY(ctx, d_ct.alloc(n * 16));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, dx[i].alloc(chunk * sx));
+        HIP_TRY(ctx, dy[i].alloc(chunk * sy));
+        HIP_TRY(ctx, dz[i].alloc(chunk * sz));
+        if (pbk && kemit) {
+            HIP_TRY(ctx, dw[i].alloc(chunk * WORDS_ROWS));
+            HIP_TRY(ctx, dkx[i].alloc(chunk * kxs));
+            HIP_TRY(ctx, dky[i].alloc(chunk * kys));
+            HIP_TRY(ctx, dkz[i].alloc(chunk * kzs));
+        }
+    }
+    Pinned px, py, pz;
+    px.pin(x, n * sx); py.pin(y, n * sy); pz.pin(z, n * sz);
+    HIP_TRY(ctx, hipMemcpyAsync(d_pt.p, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
+    HIP_TRY(ctx, hipMemcpyAsync(d_keys.p, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
+
+    if (!pbk && kemit) {
+        // shared key: one key slab, straight through
+        DevBuf w1, kx1, ky1, kz1;
+        HIP_TRY(ctx, w1.alloc(WORDS_ROWS)); HIP_TRY(ctx, kx1.alloc(kxs)); HIP_TRY(ctx, ky1.alloc(kys)); HIP_TRY(ctx, kz1.alloc(kzs));
+        rc = aesw_key_schedule_witness_device(ctx, d_keys.p, 1, layout, w1.p, kx1.p, ky1.p, kz1.p, nullptr, ctx->s_compute);
+        if (rc != AESW_OK) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->s_compute));
+        if (ks->w) HIP_TRY(ctx, hipMemcpy(ks->w, w1.p, WORDS_ROWS, hipMemcpyDeviceToHost));
+        if (ks->kx) HIP_TRY(ctx, hipMemcpy(ks->kx, kx1.p, kxs, hipMemcpyDeviceToHost));
+        if (ks->ky) HIP_TRY(ctx, hipMemcpy(ks->ky, ky1.p, kys, hipMemcpyDeviceToHost));
+        if (ks->kz) HIP_TRY(ctx, hipMemcpy(ks->kz, kz1.p, kzs, hipMemcpyDeviceToHost));
+    }
+
+    hipEvent_t done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    struct EvGuard {
+        hipEvent_t *a, *b;
+        ~EvGuard() { for (int i = 0; i < 2; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } }
+    } evg{done, copied};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+    }
+    uint64_t b0 = 0;
+    int it = 0;
+    while (b0 < n) {
+        const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
+        const int s = it & 1;
+        if (it >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_compute, copied[s], 0));  // buffer set free again
+        aesw_key_slab dks{dw[s].p, dkx[s].p, dky[s].p, dkz[s].p};
+        rc = aesw_encrypt_witness_device(ctx, d_pt.p + 16 * b0, pbk ? d_keys.p + 16 * b0 : d_keys.p, per_block_keys, m,
+                                         layout, dx[s].p, dy[s].p, dz[s].p, ct ? d_ct.p + 16 * b0 : nullptr,
+                                         pbk && kemit ? &dks : nullptr, ctx->s_compute);
+        if (rc != AESW_OK) return rc;
+        HIP_TRY(ctx, hipEventRecord(done[s], ctx->s_compute));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(x + b0 * sx, dx[s].p, m * sx, hipMemcpyDeviceToHost, ctx->s_copy));
+        HIP_TRY(ctx, hipMemcpyAsync(y + b0 * sy, dy[s].p, m * sy, hipMemcpyDeviceToHost, ctx->s_copy));
+        HIP_TRY(ctx, hipMemcpyAsync(z + b0 * sz, dz[s].p, m * sz, hipMemcpyDeviceToHost, ctx->s_copy));
+        if (pbk && kemit) {
+            if (ks->w) HIP_TRY(ctx, hipMemcpyAsync(ks->w + b0 * WORDS_ROWS, dw[s].p, m * WORDS_ROWS, hipMemcpyDeviceToHost, ctx->s_copy));
+            if (ks->kx) HIP_TRY(ctx, hipMemcpyAsync(ks->kx + b0 * kxs, dkx[s].p, m * kxs, hipMemcpyDeviceToHost, ctx->s_copy));
+            if (ks->ky) HIP_TRY(ctx, hipMemcpyAsync(ks->ky + b0 * kys, dky[s].p, m * kys, hipMemcpyDeviceToHost, ctx->s_copy));
+            if (ks->kz) HIP_TRY(ctx, hipMemcpyAsync(ks->kz + b0 * kzs, dkz[s].p, m * kzs, hipMemcpyDeviceToHost, ctx->s_copy));
+        }
+        HIP_TRY(ctx, hipEventRecord(copied[s], ctx->s_copy));
+        b0 += m;
+        ++it;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_copy));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_compute));
+    if (ct) HIP_TRY(ctx, hipMemcpy(ct, d_ct.p, n * 16, hipMemcpyDeviceToHost));
+    return AESW_OK;
+}
+
+int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout, uint8_t *w, uint8_t *kx,
+                              uint8_t *ky, uint8_t *kz, uint8_t *rk) {
+    if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;
+    if (n == 0) return AESW_OK;
+    if (!keys) return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    const size_t kxs = aesw_key_column_stride(layout, 0), kys = aesw_key_column_stride(layout, 1),
+                 kzs = aesw_key_column_stride(layout, 2);
+    DevBuf dk, dw, dkx, dky, dkz, drk;
+    HIP_TRY(ctx, dk.alloc(n * 16));
+    if (w) HIP_TRY(ctx, dw.alloc(n * WORDS_ROWS));
+    if (kx) HIP_TRY(ctx, dkx.alloc(n * kxs));
+    if (ky) HIP_TRY(ctx, dky.alloc(n * kys));
+    if (kz) HIP_TRY(ctx, dkz.alloc(n * kzs));
+    if (rk) HIP_TRY(ctx, drk.alloc(n * RK_BYTES));
+    HIP_TRY(ctx, hipMemcpy(dk.p, keys, n * 16, hipMemcpyHostToDevice));
+    int rc = aesw_key_schedule_witness_device(ctx, dk.p, n, layout, w ? dw.p : nullptr, kx ? dkx.p : nullptr,
+                                              ky ? dky.p : nullptr, kz ? dkz.p : nullptr, rk ? drk.p : nullptr, nullptr);
+    if (rc != AESW_OK) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (w) HIP_TRY(ctx, hipMemcpy(w, dw.p, n * WORDS_ROWS, hipMemcpyDeviceToHost));
+    if (kx) HIP_TRY(ctx, hipMemcpy(kx, dkx.p, n * kxs, hipMemcpyDeviceToHost));
+    if (ky) HIP_TRY(ctx, hipMemcpy(ky, dky.p, n * kys, hipMemcpyDeviceToHost));
+    if (kz) HIP_TRY(ctx, hipMemcpy(kz, dkz.p, n * kzs, hipMemcpyDeviceToHost));
+    if (rk) HIP_TRY(ctx, hipMemcpy(rk, drk.p, n * RK_BYTES, hipMemcpyDeviceToHost));
+    return AESW_OK;
+}
+
+int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3) {
+    if (!ctx || !t0 || !t1 || !t2 || !t3) return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    DevBuf d;
+    HIP_TRY(ctx, d.alloc(4 * (size_t)AESW_TABLE_ROWS));
+    uint8_t *p = d.p;
+    int rc = aesw_lookup_table_device(ctx, p, p + AESW_TABLE_ROWS, p + 2 * (size_t)AESW_TABLE_ROWS,
+                                      p + 3 * (size_t)AESW_TABLE_ROWS, nullptr);
+    if (rc != AESW_OK) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    uint8_t *outs[4] = {t0, t1, t2, t3};
+    for (int i = 0; i < 4; ++i)
+        HIP_TRY(ctx, hipMemcpy(outs[i], p + i * (size_t)AESW_TABLE_ROWS, AESW_TABLE_ROWS, hipMemcpyDeviceToHost));
+    return AESW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// aesw_internal.h -- kernel parameter blocks and launchers shared by
+// aesw_kernels.hip and aesw_api.cpp (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aesw {
+
+struct KeyOut {
+    uint8_t *w, *kx, *ky, *kz;  // any may be null
+};
+
+struct EncParams {
+    const uint8_t *pt;      // n*16
+    const uint8_t *keys;    // 16 or n*16
+    const uint8_t *tables;  // 768: sbox | mul2 | mul3
+    uint8_t *x, *y, *z;     // column buffers (16-byte aligned)
+    uint8_t *ct;            // n*16 or null
+    KeyOut key;             // per-block-key mode only
+    uint64_t n;
+};
+
+struct KeyParams {
+    const uint8_t *keys;  // n*16
+    const uint8_t *tables;
+    KeyOut key;
+    uint8_t *rk;  // n*176 or null
+    uint64_t n;
+};
+
+hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, bool pbk, bool kemit, int waves, bool nt,
+                          hipStream_t s);
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool nt, hipStream_t s);
+hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
+hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, hipStream_t s);
+
+}  // namespace aesw

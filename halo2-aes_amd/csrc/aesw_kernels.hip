@@ -1,0 +1,467 @@
+// aesw_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the batched AES-128
+// witness generator.  Hand-written HIP for wave64; no MFMA (pure GF(2^8)/byte
+// work, HBM-write bound).  DESIGN.md "kernels" has the rooflines.
+//
+// Decomposition
+//   lane  = one state column (4 packed bytes) of one AES block
+//   quad  = one block: ShiftRows is three DPP quad_perm moves, no LDS
+//   wave  = 16 blocks; it owns a private LDS staging slab and needs no barrier
+//   group = WAVES waves = 16*WAVES consecutive blocks (64 by default, so a
+//           group's output range is 128-byte-line aligned in every column)
+// Data flow per wave: registers -> whole dwords (v_perm_b32) -> LDS staging
+// slab laid out exactly like the output columns (bank-conflict-free strides,
+// aesw_layout.h) -> 16-byte-per-lane contiguous global stores, one segment
+// (head+round 1, rounds 2..8, round 9+10) at a time.
+// The S-box / mul2 / mul3 tables live in LDS (768 B); when the host's mul
+// tables equal GF(2^8) xtime the packed arithmetic path replaces 8 of the 12
+// lookups per round.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aesw_internal.h"
+#include "aesw_lane.h"
+
+namespace aesw {
+
+constexpr int LANES = 64;
+constexpr int BPW = 16;  // blocks per wave
+constexpr int TAB_BYTES = 768;
+constexpr int RKS_BYTES = 176;  // shared round keys in LDS
+
+// ---------------------------------------------------------------------------
+// cross-lane helpers
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// lane w of a quad reads lane (w+k)%4
+__device__ __forceinline__ uint32_t quad_rot1(uint32_t v) { return quad_perm<0x39>(v); }  // [1,2,3,0]
+__device__ __forceinline__ uint32_t quad_rot2(uint32_t v) { return quad_perm<0x4E>(v); }  // [2,3,0,1]
+__device__ __forceinline__ uint32_t quad_rot3(uint32_t v) { return quad_perm<0x93>(v); }  // [3,0,1,2]
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return quad_perm<J * 0x55>(v); }
+
+// Lanes of one wave exchange data through LDS without s_barrier: the LDS unit
+// executes a wave's DS instructions in issue order; this only stops the
+// compiler from moving the reads above the writes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------
+// sinks (see aesw_lane.h)
+// ---------------------------------------------------------------------------
+template <int L>
+struct DevSink {
+    uint8_t *lds;
+    uint32_t pb[3];  // stage + blk*STRIDE + 4w
+    uint32_t mb[3];  // stage + blk*STRIDE + MIXW*w
+    template <int C>
+    __device__ __forceinline__ void plain(int off, uint32_t v) {
+        *reinterpret_cast<uint32_t *>(lds + pb[C] + off) = v;
+    }
+    template <int C>
+    __device__ __forceinline__ void mix(int off, int k, uint32_t v) {
+        *reinterpret_cast<uint32_t *>(lds + mb[C] + off + 4 * k) = v;
+    }
+};
+
+struct DevKSink {
+    uint8_t *lds;
+    uint32_t bx, by, bz, bw;  // stage + blk*stride
+    __device__ __forceinline__ void kx(int off, uint32_t v) { *reinterpret_cast<uint32_t *>(lds + bx + off) = v; }
+    __device__ __forceinline__ void ky(int off, uint32_t v) { *reinterpret_cast<uint32_t *>(lds + by + off) = v; }
+    __device__ __forceinline__ void kz(int off, uint32_t v) { *reinterpret_cast<uint32_t *>(lds + bz + off) = v; }
+    __device__ __forceinline__ void words(int off, uint32_t v) { *reinterpret_cast<uint32_t *>(lds + bw + off) = v; }
+};
+
+struct NullKSink {
+    __device__ __forceinline__ void kx(int, uint32_t) {}
+    __device__ __forceinline__ void ky(int, uint32_t) {}
+    __device__ __forceinline__ void kz(int, uint32_t) {}
+    __device__ __forceinline__ void words(int, uint32_t) {}
+};
+
+// ---------------------------------------------------------------------------
+// LDS -> HBM
+// ---------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int PIECE> struct PieceT;
+template <> struct PieceT<16> { using type = u32x4; };
+template <> struct PieceT<8> { using type = u32x2; };
+template <> struct PieceT<4> { using type = uint32_t; };
+
+template <bool NT, class V>
+__device__ __forceinline__ void gstore(V *p, const V &v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// Per-block runs: block b of the wave contributes LEN bytes at LDS
+// stage + b*LSTRIDE, going to g + b*GSTRIDE.  Consecutive lanes take
+// consecutive PIECE-byte pieces of a run, then the next block's run.
+template <int PIECE, int LEN, int LSTRIDE, int GSTRIDE, bool NT>
+__device__ __forceinline__ void flush_runs(const uint8_t *lds, uint32_t stage, uint8_t *g, int nvalid, int lane) {
+    using V = typename PieceT<PIECE>::type;
+    static_assert(LEN % PIECE == 0 && LSTRIDE % PIECE == 0 && GSTRIDE % PIECE == 0, "piece alignment");
+    constexpr int PPB = LEN / PIECE;
+    constexpr int TOTAL = BPW * PPB;
+#pragma unroll
+    for (int p0 = 0; p0 < TOTAL; p0 += LANES) {
+        const int p = p0 + lane;
+        const int blk = p / PPB;
+        const int q = p - blk * PPB;
+        if (p < TOTAL && blk < nvalid) {
+            const V v = *reinterpret_cast<const V *>(lds + stage + blk * LSTRIDE + q * PIECE);
+            gstore<NT>(reinterpret_cast<V *>(g + (size_t)blk * GSTRIDE + q * PIECE), v);
+        }
+    }
+}
+
+// Fully contiguous: nvalid*STRIDE bytes from LDS stage to g.
+template <int PIECE, int STRIDE, bool NT>
+__device__ __forceinline__ void flush_contig(const uint8_t *lds, uint32_t stage, uint8_t *g, int nvalid, int lane) {
+    using V = typename PieceT<PIECE>::type;
+    static_assert(STRIDE % PIECE == 0, "piece alignment");
+    constexpr int TOTAL = BPW * STRIDE / PIECE;
+    const int valid = nvalid * (STRIDE / PIECE);
+#pragma unroll
+    for (int p0 = 0; p0 < TOTAL; p0 += LANES) {
+        const int p = p0 + lane;
+        if (p < valid) {
+            const V v = *reinterpret_cast<const V *>(lds + stage + p * PIECE);
+            gstore<NT>(reinterpret_cast<V *>(g + (size_t)p * PIECE), v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-wave LDS footprints
+// ---------------------------------------------------------------------------
+template <int L>
+struct Stage {
+    static constexpr int SX = SegX<L>::STRIDE, SY = SegY<L>::STRIDE, SZ = SegZ<L>::STRIDE;
+    static constexpr int OX = 0, OY = BPW * SX, OZ = OY + BPW * SY;
+    static constexpr int ENC_BYTES = OZ + BPW * SZ;
+    using G = Geo<L>;
+    static constexpr int KW = 0, KX = BPW * WORDS_ROWS, KY = KX + BPW * G::KXS, KZ = KY + BPW * G::KYS;
+    static constexpr int KEY_BYTES = KZ + BPW * G::KZS;
+    static constexpr int RK_BYTES_W = BPW * RK_BYTES;  // per-block round keys of a wave
+};
+
+template <int L> __host__ __device__ constexpr int enc_wave_lds(bool pbk, bool kemit) {
+    return ((kemit && Stage<L>::KEY_BYTES > Stage<L>::ENC_BYTES) ? Stage<L>::KEY_BYTES : Stage<L>::ENC_BYTES) +
+           (pbk ? Stage<L>::RK_BYTES_W : 0);
+}
+
+// One key-schedule round for every quad of the wave.
+template <int L, class KS, class T>
+__device__ __forceinline__ uint32_t key_round_dev(KS &ks, int rho, int w, uint32_t kw, const T &tab) {
+    const uint32_t k0 = quad_bcast<0>(kw), k1 = quad_bcast<1>(kw), k2 = quad_bcast<2>(kw), k3 = quad_bcast<3>(kw);
+    return emit_key_round<L>(ks, rho, w, k0, k1, k2, k3, rcon(rho - 1), tab);
+}
+
+// Key phase of a wave: W[0..15] = key, ten rounds, round keys to rkl[blk][44].
+template <int L, bool EMIT, class T>
+__device__ __forceinline__ void key_phase(uint8_t *lds, uint32_t stage, uint32_t rk_off, uint32_t key_word, int blk,
+                                          int w, const T &tab) {
+    using G = Geo<L>;
+    using St = Stage<L>;
+    uint32_t *rkl = reinterpret_cast<uint32_t *>(lds + rk_off) + blk * 44 + w;
+    uint32_t kw = key_word;
+    rkl[0] = kw;
+    if (EMIT) {
+        DevKSink ks{lds, stage + St::KX + blk * G::KXS, stage + St::KY + blk * G::KYS, stage + St::KZ + blk * G::KZS,
+                    stage + St::KW + blk * WORDS_ROWS};
+        ks.words(4 * w, kw);  // src/key_schedule.rs:98-118
+#pragma unroll
+        for (int rho = 1; rho <= 10; ++rho) {
+            kw = key_round_dev<L>(ks, rho, w, kw, tab);
+            rkl[4 * rho] = kw;
+        }
+    } else {
+        NullKSink ks;
+#pragma unroll
+        for (int rho = 1; rho <= 10; ++rho) {
+            kw = key_round_dev<L>(ks, rho, w, kw, tab);
+            rkl[4 * rho] = kw;
+        }
+    }
+}
+
+template <int L, bool NT>
+__device__ __forceinline__ void key_flush(const uint8_t *lds, uint32_t stage, const KeyOut &o, uint64_t blk0,
+                                          int nvalid, int lane) {
+    using G = Geo<L>;
+    using St = Stage<L>;
+    if (o.w) flush_contig<16, WORDS_ROWS, NT>(lds, stage + St::KW, o.w + blk0 * WORDS_ROWS, nvalid, lane);
+    if (o.kx) flush_contig<16, G::KXS, NT>(lds, stage + St::KX, o.kx + blk0 * G::KXS, nvalid, lane);
+    if (o.ky) flush_contig<16, G::KYS, NT>(lds, stage + St::KY, o.ky + blk0 * G::KYS, nvalid, lane);
+    if (o.kz) flush_contig<(G::KZS % 16 == 0 ? 16 : 8), G::KZS, NT>(lds, stage + St::KZ, o.kz + blk0 * G::KZS, nvalid, lane);
+}
+
+// ---------------------------------------------------------------------------
+// encrypt witness kernel
+// ---------------------------------------------------------------------------
+// PBK: per-block keys (key schedule per quad; KEMIT: also emit its witness).
+// !PBK: the shared key is expanded once per group by wave 0's first quad.
+template <int L, bool XT, bool PBK, bool KEMIT, bool NT>
+__global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using G = Geo<L>;
+    using St = Stage<L>;
+    constexpr int WAVE_LDS = enc_wave_lds<L>(PBK, KEMIT);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int waves = blockDim.x >> 6;
+    const int blk = lane >> 2, w = lane & 3;
+
+    // tables -> LDS
+    if (tid < TAB_BYTES / 4)
+        reinterpret_cast<uint32_t *>(lds)[tid] = reinterpret_cast<const uint32_t *>(a.tables)[tid];
+    __syncthreads();
+    const Tables<XT> tab{lds};
+
+    const uint32_t shared_rk = TAB_BYTES;                          // 176 B, !PBK only
+    const uint32_t stage = TAB_BYTES + RKS_BYTES + wave * WAVE_LDS;  // this wave's slab
+    const uint32_t rk_w = stage + (WAVE_LDS - St::RK_BYTES_W);      // PBK only: tail of the slab
+
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * waves + wave) * BPW;
+    const int64_t left = (int64_t)a.n - (int64_t)blk0;
+    const int nvalid = left >= BPW ? BPW : (left > 0 ? (int)left : 0);
+    const bool live = blk < nvalid;
+
+    if (!PBK) {
+        if (wave == 0) {
+            const uint32_t kw = reinterpret_cast<const uint32_t *>(a.keys)[w];
+            NullKSink ks;
+            uint32_t k = kw;
+            uint32_t *rks = reinterpret_cast<uint32_t *>(lds + shared_rk);
+            if (blk == 0) rks[w] = k;
+#pragma unroll
+            for (int rho = 1; rho <= 10; ++rho) {
+                k = key_round_dev<L>(ks, rho, w, k, tab);
+                if (blk == 0) rks[4 * rho + w] = k;
+            }
+        }
+        __syncthreads();
+    }
+    if (nvalid == 0) return;
+
+    if (PBK) {
+        const uint32_t kw = live ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
+        key_phase<L, KEMIT>(lds, stage, rk_w, kw, blk, w, tab);
+        if (KEMIT) {
+            wave_lds_fence();
+            key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
+        }
+        wave_lds_fence();
+    }
+    const uint32_t *rkp = PBK ? reinterpret_cast<const uint32_t *>(lds + rk_w) + blk * 44 + w
+                              : reinterpret_cast<const uint32_t *>(lds + shared_rk) + w;
+
+    DevSink<L> s;
+    s.lds = lds;
+    s.pb[0] = stage + St::OX + blk * St::SX + 4 * w;
+    s.pb[1] = stage + St::OY + blk * St::SY + 4 * w;
+    s.pb[2] = stage + St::OZ + blk * St::SZ + 4 * w;
+    s.mb[0] = stage + St::OX + blk * St::SX + G::X_MIXW * w;
+    s.mb[1] = stage + St::OY + blk * St::SY + G::Y_MIXW * w;
+    s.mb[2] = stage + St::OZ + blk * St::SZ + G::Z_MIXW * w;
+
+    uint8_t *gx = a.x + blk0 * G::XS;
+    uint8_t *gy = a.y + blk0 * G::YS;
+    uint8_t *gz = a.z + blk0 * G::ZS;
+
+    const uint32_t ptw = live ? reinterpret_cast<const uint32_t *>(a.pt)[(blk0 + blk) * 4 + w] : 0u;
+
+    auto round = [&](int relx, int rely, int relz, uint32_t st, uint32_t rkw) -> uint32_t {
+        const uint32_t sub = emit_sbox<L>(s, relx, rely, relz, st, tab);
+        const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
+        return emit_mix_ark<L>(s, relx, rely, relz, sh, rkw, tab);
+    };
+
+    // segment 0: rows 0..31 and round 1
+    uint32_t st = emit_head<L>(s, ptw, rkp[0]);
+    st = round(G::X_HEAD, G::Y_HEAD, G::Z_HEAD, st, rkp[4]);
+    wave_lds_fence();
+    flush_runs<16, SegX<L>::len(0), St::SX, G::XS, NT>(lds, stage + St::OX, gx, nvalid, lane);
+    flush_runs<16, SegY<L>::len(0), St::SY, G::YS, NT>(lds, stage + St::OY, gy, nvalid, lane);
+    flush_runs<16, SegZ<L>::len(0), St::SZ, G::ZS, NT>(lds, stage + St::OZ, gz, nvalid, lane);
+    wave_lds_fence();
+
+    // segments 1..7: rounds 2..8
+    for (int g = 1; g <= 7; ++g) {
+        st = round(0, 0, 0, st, rkp[4 * (g + 1)]);
+        wave_lds_fence();
+        flush_runs<16, SegX<L>::len(1), St::SX, G::XS, NT>(lds, stage + St::OX, gx + SegX<L>::start(g), nvalid, lane);
+        flush_runs<16, SegY<L>::len(1), St::SY, G::YS, NT>(lds, stage + St::OY, gy + SegY<L>::start(g), nvalid, lane);
+        flush_runs<16, SegZ<L>::len(1), St::SZ, G::ZS, NT>(lds, stage + St::OZ, gz + SegZ<L>::start(g), nvalid, lane);
+        wave_lds_fence();
+    }
+
+    // segment 8: round 9 and round 10
+    st = round(0, 0, 0, st, rkp[36]);
+    {
+        const uint32_t sub = emit_sbox<L>(s, G::X_ROUND, G::Y_ROUND, G::Z_ROUND, st, tab);
+        const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
+        st = emit_final_ark<L>(s, G::X_ROUND, G::Y_ROUND, G::Z_ROUND, sh, rkp[40]);
+    }
+    wave_lds_fence();
+    flush_runs<16, SegX<L>::len(8), St::SX, G::XS, NT>(lds, stage + St::OX, gx + SegX<L>::start(8), nvalid, lane);
+    flush_runs<16, SegY<L>::len(8), St::SY, G::YS, NT>(lds, stage + St::OY, gy + SegY<L>::start(8), nvalid, lane);
+    flush_runs<16, SegZ<L>::len(8), St::SZ, G::ZS, NT>(lds, stage + St::OZ, gz + SegZ<L>::start(8), nvalid, lane);
+
+    if (a.ct && live) reinterpret_cast<uint32_t *>(a.ct)[(blk0 + blk) * 4 + w] = st;
+}
+
+// ---------------------------------------------------------------------------
+// key-schedule witness kernel (src/key_schedule.rs:80-224 for n keys)
+// ---------------------------------------------------------------------------
+template <int L, bool XT, bool NT>
+__global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    using St = Stage<L>;
+    constexpr int WAVE_LDS = St::KEY_BYTES + St::RK_BYTES_W;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
+    const int blk = lane >> 2, w = lane & 3;
+    if (tid < TAB_BYTES / 4)
+        reinterpret_cast<uint32_t *>(lds)[tid] = reinterpret_cast<const uint32_t *>(a.tables)[tid];
+    __syncthreads();
+    const Tables<XT> tab{lds};
+    const uint32_t stage = TAB_BYTES + wave * WAVE_LDS;
+    const uint32_t rk_w = stage + St::KEY_BYTES;
+    const uint64_t blk0 = ((uint64_t)blockIdx.x * waves + wave) * BPW;
+    const int64_t left = (int64_t)a.n - (int64_t)blk0;
+    const int nvalid = left >= BPW ? BPW : (left > 0 ? (int)left : 0);
+    if (nvalid == 0) return;
+    const uint32_t kw = blk < nvalid ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
+    key_phase<L, true>(lds, stage, rk_w, kw, blk, w, tab);
+    wave_lds_fence();
+    key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
+    if (a.rk) flush_contig<16, RK_BYTES, NT>(lds, rk_w, a.rk + blk0 * RK_BYTES, nvalid, lane);
+}
+
+// ---------------------------------------------------------------------------
+// lookup table (src/table.rs:18-192): 66561 rows x 4 byte columns
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) table_kernel(const uint8_t *__restrict__ tables, uint8_t *t0, uint8_t *t1,
+                                                   uint8_t *t2, uint8_t *t3) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 66561u) return;
+    uint8_t tag, a, b, c;
+    if (r < 256u) { tag = 1; a = (uint8_t)r; b = 0; c = 0; }                                         // Tag::U8   :27-53
+    else if (r < 512u) { const uint32_t i = r - 256u; tag = 3; a = (uint8_t)i; b = tables[i]; c = 0; }  // Tag::Sbox :57-83
+    else if (r < 66048u) { const uint32_t l = r - 512u; tag = 2; a = (uint8_t)(l >> 8); b = (uint8_t)l; c = a ^ b; }  // Tag::Xor :88-116
+    else if (r < 66304u) { const uint32_t i = r - 66048u; tag = 4; a = (uint8_t)i; b = tables[256 + i]; c = 0; }      // GfMul2 :120-145
+    else if (r < 66560u) { const uint32_t i = r - 66304u; tag = 5; a = (uint8_t)i; b = tables[512 + i]; c = 0; }      // GfMul3 :149-174
+    else { tag = 0; a = 0; b = 0; c = 0; }                                                           // empty row :178-187
+    t0[r] = tag; t1[r] = a; t2[r] = b; t3[r] = c;
+}
+
+// ---------------------------------------------------------------------------
+// byte cells -> bn256::Fr Montgomery cells
+// ---------------------------------------------------------------------------
+// fr_lut: 256 x 32 B (value v -> v*R mod p, little-endian), built on the host.
+// One lane writes one 16-byte half cell, so a wave stores 1 KiB contiguously.
+__global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restrict__ cells, uint64_t n_cells,
+                                                       const u32x4 *__restrict__ fr_lut, u32x4 *__restrict__ out) {
+    __shared__ u32x4 lut[512];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) lut[i] = fr_lut[i];
+    __syncthreads();
+    const uint64_t total = n_cells * 2;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint32_t v = cells[i >> 1];
+        out[i] = lut[v * 2 + (uint32_t)(i & 1)];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+template <int L, bool XT, bool PBK, bool KEMIT, bool NT>
+static hipError_t launch_enc(const EncParams &p, int waves, hipStream_t stream) {
+    const int bpg = waves * BPW;
+    const uint64_t groups = (p.n + bpg - 1) / bpg;
+    if (groups == 0) return hipSuccess;
+    if (groups > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(PBK, KEMIT);
+    auto k = encrypt_kernel<L, XT, PBK, KEMIT, NT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)groups), dim3(waves * LANES), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int L, bool XT, bool PBK, bool KEMIT>
+static hipError_t launch_enc_nt(const EncParams &p, int waves, bool nt, hipStream_t s) {
+    return nt ? launch_enc<L, XT, PBK, KEMIT, true>(p, waves, s) : launch_enc<L, XT, PBK, KEMIT, false>(p, waves, s);
+}
+
+template <int L, bool XT>
+static hipError_t launch_enc_mode(const EncParams &p, bool pbk, bool kemit, int waves, bool nt, hipStream_t s) {
+    if (!pbk) return launch_enc_nt<L, XT, false, false>(p, waves, nt, s);
+    return kemit ? launch_enc_nt<L, XT, true, true>(p, waves, nt, s) : launch_enc_nt<L, XT, true, false>(p, waves, nt, s);
+}
+
+hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, bool pbk, bool kemit, int waves, bool nt,
+                          hipStream_t s) {
+    if (waves < 1 || waves > 4) return hipErrorInvalidValue;
+    if (layout == DENSE)
+        return xt ? launch_enc_mode<DENSE, true>(p, pbk, kemit, waves, nt, s)
+                  : launch_enc_mode<DENSE, false>(p, pbk, kemit, waves, nt, s);
+    return xt ? launch_enc_mode<PACKED, true>(p, pbk, kemit, waves, nt, s)
+              : launch_enc_mode<PACKED, false>(p, pbk, kemit, waves, nt, s);
+}
+
+template <int L, bool XT, bool NT>
+static hipError_t launch_key_t(const KeyParams &p, int waves, hipStream_t stream) {
+    const int bpg = waves * BPW;
+    const uint64_t groups = (p.n + bpg - 1) / bpg;
+    if (groups == 0) return hipSuccess;
+    if (groups > 0x7fffffffull) return hipErrorInvalidValue;
+    const size_t lds = TAB_BYTES + (size_t)waves * (Stage<L>::KEY_BYTES + Stage<L>::RK_BYTES_W);
+    auto k = key_kernel<L, XT, NT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)groups), dim3(waves * LANES), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool nt, hipStream_t s) {
+    if (waves < 1 || waves > 4) return hipErrorInvalidValue;
+    if (layout == DENSE) {
+        if (xt) return nt ? launch_key_t<DENSE, true, true>(p, waves, s) : launch_key_t<DENSE, true, false>(p, waves, s);
+        return nt ? launch_key_t<DENSE, false, true>(p, waves, s) : launch_key_t<DENSE, false, false>(p, waves, s);
+    }
+    if (xt) return nt ? launch_key_t<PACKED, true, true>(p, waves, s) : launch_key_t<PACKED, true, false>(p, waves, s);
+    return nt ? launch_key_t<PACKED, false, true>(p, waves, s) : launch_key_t<PACKED, false, false>(p, waves, s);
+}
+
+hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s) {
+    hipLaunchKernelGGL(table_kernel, dim3((66561 + 255) / 256), dim3(256), 0, s, tables, t0, t1, t2, t3);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, hipStream_t s) {
+    if (n_cells == 0) return hipSuccess;
+    uint64_t blocks = (n_cells * 2 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(expand_fr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells,
+                       reinterpret_cast<const u32x4 *>(fr_lut), reinterpret_cast<u32x4 *>(out));
+    return hipGetLastError();
+}
+
+}  // namespace aesw

@@ -1,0 +1,119 @@
+// aesw_layout.h -- geometry of the witness slabs, shared by the HIP kernels, the
+// C ABI's pure-host helpers and the host-side lane model used by the tests.
+//
+// The slab map is derived from the reference's region call order
+// (src/aes128.rs:154-301, src/key_schedule.rs:80-224); DESIGN.md "slab map"
+// spells it out.  Nothing here is copied from the reference: the numbers are
+// byte offsets of OUR column-major buffers.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define AESW_HD __host__ __device__ __forceinline__
+#else
+#define AESW_HD inline
+#endif
+
+namespace aesw {
+
+enum : int { DENSE = 0, PACKED = 1 };
+
+constexpr int AES_ROWS = 1360;  // src/constant.rs:114
+constexpr int KEY_ROWS = 400;   // 10 rounds x 40 one-row chip regions (src/key_schedule.rs:122-224)
+constexpr int WORDS_ROWS = 96;  // 16 + 10 x (4 + 4) rows of words_column
+constexpr int RK_BYTES = 176;   // 11 round keys
+
+// ---- encrypt slab -----------------------------------------------------------
+// Per column: HEAD bytes (rows 0..31: plaintext rows + initial AddRoundKey,
+// src/aes128.rs:176-198), nine ROUND-sized pieces (rounds 1..9, :201-262) and
+// TAIL bytes (round 10).  Inside a round: SBOX rows, 16 lcon() records of
+// MIXW/4... bytes per lane-word, ARK rows.
+template <int L>
+struct Geo {
+    // bytes per block
+    static constexpr int XS = 1360;
+    static constexpr int YS = L == DENSE ? 1360 : 1056;
+    static constexpr int ZS = L == DENSE ? 1360 : 608;
+    // head / round / tail bytes
+    static constexpr int X_HEAD = 32, X_ROUND = 144, X_TAIL = 32;
+    static constexpr int Y_HEAD = L == DENSE ? 32 : 16, Y_ROUND = L == DENSE ? 144 : 112, Y_TAIL = 32;
+    static constexpr int Z_HEAD = L == DENSE ? 32 : 16, Z_ROUND = L == DENSE ? 144 : 64,
+                         Z_TAIL = L == DENSE ? 32 : 16;
+    // offsets inside the head (relative to the head start)
+    static constexpr int X_H_PT = 0, X_H_ARK = 16;        // rows 0..15 pt, rows 16..31 pt again
+    static constexpr int Y_H_ARK = L == DENSE ? 16 : 0;   // rk0
+    static constexpr int Z_H_ARK = L == DENSE ? 16 : 0;   // pt ^ rk0
+    // offsets inside a round (relative to the round start)
+    static constexpr int X_SBOX = 0, X_MIX = 16, X_MIXW = 28, X_ARK = 128;
+    static constexpr int Y_SBOX = 0, Y_MIX = 16, Y_MIXW = L == DENSE ? 28 : 20, Y_ARK = L == DENSE ? 128 : 96;
+    static constexpr int Z_SBOX = 0 /* dense only: zeros */, Z_MIX = L == DENSE ? 16 : 0,
+                         Z_MIXW = L == DENSE ? 28 : 12, Z_ARK = L == DENSE ? 128 : 48;
+    // offsets inside the tail (round 10: sbox rows, then ShiftRows ^ rk10)
+    static constexpr int X_T_SBOX = 0, X_T_ARK = 16;
+    static constexpr int Y_T_SBOX = 0, Y_T_ARK = 16;
+    static constexpr int Z_T_ARK = L == DENSE ? 16 : 0;
+    // dwords per lcon record group of one lane-word (4 output bytes x 7 rows)
+    static constexpr int X_MIXD = 7, Y_MIXD = L == DENSE ? 7 : 5, Z_MIXD = L == DENSE ? 7 : 3;
+
+    // ---- key slab (per key): rounds of KX_ROUND bytes, no head
+    static constexpr int KXS = 400;
+    static constexpr int KYS = L == DENSE ? 400 : 240;
+    static constexpr int KZS = L == DENSE ? 400 : 200;
+    static constexpr int KX_ROUND = 40, KY_ROUND = L == DENSE ? 40 : 24, KZ_ROUND = L == DENSE ? 40 : 20;
+    // kz packed drops rows 0..3 of every round (sbox rows have no z)
+    static constexpr int KZ_SHIFT = L == DENSE ? 0 : 4;
+};
+
+// Flush segments: the encrypt slab leaves LDS in 9 pieces per column --
+// segment 0 = head + round 1, segments 1..7 = rounds 2..8, segment 8 = round 9
+// + round 10 -- so every piece is a multiple of 16 bytes in both layouts.
+constexpr int N_SEG = 9;
+template <int HEAD, int ROUND, int TAIL>
+struct Seg {
+    static constexpr int STRIDE = ROUND + (HEAD > TAIL ? HEAD : TAIL);  // LDS bytes per block
+    AESW_HD static constexpr int start(int g) { return g == 0 ? 0 : HEAD + ROUND * g; }
+    AESW_HD static constexpr int len(int g) { return ROUND + (g == 0 ? HEAD : 0) + (g == N_SEG - 1 ? TAIL : 0); }
+};
+template <int L> using SegX = Seg<Geo<L>::X_HEAD, Geo<L>::X_ROUND, Geo<L>::X_TAIL>;
+template <int L> using SegY = Seg<Geo<L>::Y_HEAD, Geo<L>::Y_ROUND, Geo<L>::Y_TAIL>;
+template <int L> using SegZ = Seg<Geo<L>::Z_HEAD, Geo<L>::Z_ROUND, Geo<L>::Z_TAIL>;
+
+// MixColumns matrix rows as the reference writes them (src/aes128.rs:228-233).
+constexpr int MIX[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};
+
+// Pure-host: which dense rows of the encrypt slab are assigned, per column.
+// Built from the same description the kernels use; the tests compare it with
+// the mask the oracle derives by running the reference's call order.
+inline void encrypt_assigned_mask(int col, uint8_t mask[AES_ROWS]) {
+    for (int r = 0; r < AES_ROWS; ++r) mask[r] = 0;
+    auto set = [&](int r, bool x, bool y, bool z) {
+        if ((col == 0 && x) || (col == 1 && y) || (col == 2 && z)) mask[r] = 1;
+    };
+    for (int i = 0; i < 16; ++i) set(i, true, false, false);
+    for (int i = 0; i < 16; ++i) set(16 + i, true, true, true);
+    for (int R = 1; R <= 9; ++R) {
+        const int B = 32 + 144 * (R - 1);
+        for (int i = 0; i < 16; ++i) set(B + i, true, true, false);
+        for (int k = 0; k < 16; ++k) {
+            const int m = k & 3;
+            for (int t = 0; t < 4; ++t) set(B + 16 + 7 * k + t, true, MIX[m][t] != 1, false);
+            for (int t = 4; t < 7; ++t) set(B + 16 + 7 * k + t, true, true, true);
+        }
+        for (int i = 0; i < 16; ++i) set(B + 128 + i, true, true, true);
+    }
+    for (int i = 0; i < 16; ++i) set(1328 + i, true, true, false);
+    for (int i = 0; i < 16; ++i) set(1344 + i, true, true, true);
+}
+
+inline void key_assigned_mask(int col, uint8_t mask[KEY_ROWS]) {
+    for (int r = 0; r < KEY_ROWS; ++r) mask[r] = 0;
+    for (int rho = 0; rho < 10; ++rho) {
+        const int B = 40 * rho;
+        for (int r = 0; r < 40; ++r) {
+            const bool x = true, y = r < 24, z = r >= 4 && r < 24;
+            if ((col == 0 && x) || (col == 1 && y) || (col == 2 && z)) mask[B + r] = 1;
+        }
+    }
+}
+
+}  // namespace aesw

@@ -1,0 +1,152 @@
+/*
+ * aesw.h -- C ABI of the MI355X batched witness generator for the
+ * tkmct/halo2-aes AES-128 gadget.
+ *
+ * The reference has no FFI at all (no `extern`, no `unsafe`): this header IS
+ * the seam a Rust host would bind (INTEGRATION.md shows the `extern "C"` block
+ * and the forked chips).  Each entry point names the reference code whose
+ * *values* it produces; the host keeps configure()/synthesize() and assigns
+ * the bytes returned here verbatim:
+ *
+ *   value source replaced                         reference file:line
+ *   ------------------------------------------   -------------------------------
+ *   plaintext literal                             src/aes128.rs:187
+ *   U8XorChip::xor      z = x ^ y                 src/chips/u8_xor_chip.rs:85-95
+ *   SboxChip::substitute y = S_BOX[x]             src/chips/sbox_chip.rs:73-78
+ *   MulBy{2,3}Chip::mul  y = MUL_BY_n[x]          src/chips/gf_mul_chip.rs:75-84
+ *   key literal / rcon / zero pads                src/key_schedule.rs:112,161,174,182
+ *   every copy_advice target (same value)         src/aes128.rs:285, chips
+ *   load_enc_full_table                           src/table.rs:18-192
+ *   aes_callable placement                        src/aes128.rs:303-325
+ *
+ * Conventions: plain pointers and sizes, caller-owned buffers, int status
+ * (0 = AESW_OK), no exceptions across the boundary, no global mutable state
+ * besides the opaque context.  A context is thread-compatible, not thread-safe.
+ * The library needs a gfx950 device: there is NO CPU fallback -- every entry
+ * point that computes returns AESW_ERR_NO_DEVICE / AESW_ERR_HIP instead.
+ *
+ * Witness layout ("slab"): for block b the encrypt witness is 1360 rows
+ * (AES_ROWS, src/constant.rs:114) of the three advice columns x,y,z of one
+ * column set (src/aes128.rs:54-60), in the order the reference's regions are
+ * placed (DESIGN.md "slab map").  Column buffers are column-major: column c of
+ * block b starts at c_buf + b * aesw_column_stride(layout, c).
+ *   AESW_LAYOUT_DENSE : stride 1360 for x,y,z; a cell the reference never
+ *                       assigns holds 0 (what the prover sees).
+ *   AESW_LAYOUT_PACKED: only assigned cells, in row order: strides 1360/1056/608;
+ *                       aesw_packed_index() gives dense row -> packed index.
+ * The key-schedule witness per key is words_column (96 rows,
+ * src/key_schedule.rs:98-187) plus 400 rows of set 0's x,y,z
+ * (dense 400/400/400, packed 400/240/200).
+ */
+#ifndef AESW_H
+#define AESW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AESW_VERSION 100 /* 0.1.0 */
+
+#define AESW_AES_ROWS 1360u          /* src/constant.rs:114 */
+#define AESW_KEY_SCHEDULE_ROWS 1760u /* src/constant.rs:113 (capacity constant only) */
+#define AESW_KEY_ROWS 400u           /* rows schedule_keys() really uses in set 0 */
+#define AESW_WORDS_ROWS 96u          /* rows used in words_column */
+#define AESW_TABLE_ROWS 66561u       /* src/table.rs:27-187 */
+#define AESW_FR_BYTES 32u            /* one bn256::Fr cell, little-endian Montgomery */
+
+enum aesw_status {
+    AESW_OK = 0,
+    AESW_ERR_INVALID_ARG = 1,
+    AESW_ERR_NO_DEVICE = 2, /* no gfx950 GPU / device index out of range */
+    AESW_ERR_HIP = 3,       /* a HIP runtime call failed; see aesw_last_error() */
+    AESW_ERR_NOMEM = 4,
+    AESW_ERR_CAPACITY = 5,  /* the reference panics: "AES calls too many" src/aes128.rs:160-162 */
+    AESW_ERR_NO_KEY = 6,    /* the reference panics: "Keys should be scheduled" src/aes128.rs:170 */
+    AESW_ERR_MISMATCH = 7,  /* host value disagrees with the device witness (Error::Synthesis) */
+    AESW_ERR_UNSATISFIED = 8
+};
+
+enum aesw_layout { AESW_LAYOUT_DENSE = 0, AESW_LAYOUT_PACKED = 1 };
+enum aesw_column { AESW_COL_X = 0, AESW_COL_Y = 1, AESW_COL_Z = 2 };
+
+typedef struct aesw_ctx aesw_ctx;
+
+/* Optional key-schedule witness outputs of a per-block-key encrypt call. */
+typedef struct aesw_key_slab {
+    uint8_t *w;  /* n * 96 */
+    uint8_t *kx; /* n * aesw_key_column_stride(layout, 0) */
+    uint8_t *ky;
+    uint8_t *kz;
+} aesw_key_slab;
+
+int aesw_version(void);
+const char *aesw_strerror(int status);
+/* Text of the last HIP failure seen by this context ("" if none). */
+const char *aesw_last_error(const aesw_ctx *ctx);
+int aesw_device_count(int *count);
+
+/* Tables come IN from the host's constants (src/constant.rs:1-47) so the
+ * device is bit-exact with whatever the host's lookup table holds, including
+ * the reference's S_BOX[255]==23.  device = HIP device ordinal. */
+int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8_t mul2[256],
+                const uint8_t mul3[256]);
+void aesw_destroy(aesw_ctx *ctx);
+int aesw_device(const aesw_ctx *ctx);
+
+/* ---- geometry (pure host, no device needed) ------------------------------ */
+uint32_t aesw_column_stride(int layout, int col);     /* encrypt slab, bytes per block */
+uint32_t aesw_key_column_stride(int layout, int col); /* key slab, bytes per key */
+/* dense row -> packed index (or -1 if the reference never assigns the cell) */
+int aesw_packed_index(int col, int32_t idx[AESW_AES_ROWS]);
+int aesw_key_packed_index(int col, int32_t idx[AESW_KEY_ROWS]);
+/* FixedAes128Config::aes_callable (src/aes128.rs:303-325) as a pure function:
+ * (set, first row) of the b-th encrypt() call in a K/N circuit; set 0 blocks
+ * start behind the 400 key rows.  AESW_ERR_CAPACITY when the reference panics. */
+int aesw_block_placement(uint32_t k, uint32_t n_sets, uint64_t b, uint32_t *set, uint64_t *row);
+uint64_t aesw_block_capacity(uint32_t k, uint32_t n_sets);
+
+/* ---- device-pointer entry points (asynchronous on `stream`) -------------- */
+/* stream is a hipStream_t passed as void* (NULL = the default stream).
+ * d_keys: 16 B when !per_block_keys, n*16 B otherwise.  d_ct and key_slab are
+ * optional (NULL).  All pointers are device pointers on aesw_device(ctx). */
+int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys,
+                                int per_block_keys, uint64_t n, int layout, uint8_t *d_x,
+                                uint8_t *d_y, uint8_t *d_z, uint8_t *d_ct,
+                                const aesw_key_slab *d_key_slab, void *stream);
+/* src/key_schedule.rs:80-224 for n keys.  d_rk optional: n*176 round-key bytes. */
+int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint64_t n, int layout,
+                                     uint8_t *d_w, uint8_t *d_kx, uint8_t *d_ky, uint8_t *d_kz,
+                                     uint8_t *d_rk, void *stream);
+/* src/table.rs:18-192: the four table columns as bytes (every value < 256). */
+int aesw_lookup_table_device(aesw_ctx *ctx, uint8_t *d_t0, uint8_t *d_t1, uint8_t *d_t2,
+                             uint8_t *d_t3, void *stream);
+/* Byte cells -> bn256::Fr cells (what Fp::from(u64) builds, src/utils.rs:23,
+ * src/aes128.rs:187): 32-byte little-endian Montgomery form, n_cells*32 B out. */
+int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cells, uint8_t *d_fr,
+                          void *stream);
+
+/* ---- host-pointer entry points (synchronous) ----------------------------- */
+/* Same contracts with host buffers; copies are chunked and overlapped with the
+ * kernels on two streams (config 5 of BASELINE.json). */
+int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys,
+                         uint64_t n, int layout, uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct,
+                         const aesw_key_slab *key_slab);
+int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout,
+                              uint8_t *w, uint8_t *kx, uint8_t *ky, uint8_t *kz, uint8_t *rk);
+int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3);
+
+/* ---- tuning / introspection (bench.py, tests) ----------------------------- */
+/* name: "variant" (kernel variant id), "nt_stores" (0/1).  Unknown -> INVALID_ARG */
+int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
+int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);
+/* 1 when mul2/mul3 passed to aesw_create() equal GF(2^8) xtime tables, so the
+ * arithmetic MixColumns path is used instead of LDS table lookups. */
+int aesw_uses_xtime_path(const aesw_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
