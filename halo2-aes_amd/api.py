@@ -76,6 +76,14 @@ def load_library(path: Path | None = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = Path(path) if path else LIB_PATH
+    # torch ships its own libamdhip64.so.7 and dlopen()s it by path.  Import it
+    # FIRST so libaesw.so's NEEDED libamdhip64.so.7 binds to that copy: two HIP
+    # runtimes in one process do not share the device (hipGetDeviceCount fails
+    # in the second one).  A host without torch (the Rust caller) uses /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not p.exists():
         raise FileNotFoundError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -8,10 +8,12 @@
 //   wave  = 16 blocks; it owns a private LDS staging slab and needs no barrier
 //   group = WAVES waves = 16*WAVES consecutive blocks (64 by default, so a
 //           group's output range is 128-byte-line aligned in every column)
-// Data flow per wave: registers -> whole dwords (v_perm_b32) -> LDS staging
-// slab laid out exactly like the output columns (bank-conflict-free strides,
-// aesw_layout.h) -> 16-byte-per-lane contiguous global stores, one segment
-// (head+round 1, rounds 2..8, round 9+10) at a time.
+// Data flow per wave: registers -> whole dwords (v_perm_b32) -> per-block LDS
+// staging windows (aesw_layout.h Win<>: permanent head + round slots,
+// bank-conflict-free strides) -> after every round, the 128-byte lines of the
+// output columns that just became complete leave as whole lines, 8 lanes x 16 B
+// per line, 8 lines per store instruction.  Partial-line stores are what caps a
+// naive per-round flush at ~3 TB/s; whole lines reach ~5.5 TB/s (tools/storebench).
 // The S-box / mul2 / mul3 tables live in LDS (768 B); when the host's mul
 // tables equal GF(2^8) xtime the packed arithmetic path replaces 8 of the 12
 // lookups per round.
@@ -101,23 +103,24 @@ __device__ __forceinline__ void gstore(V *p, const V &v) {
     else *p = v;
 }
 
-// Per-block runs: block b of the wave contributes LEN bytes at LDS
-// stage + b*LSTRIDE, going to g + b*GSTRIDE.  Consecutive lanes take
-// consecutive PIECE-byte pieces of a run, then the next block's run.
-template <int PIECE, int LEN, int LSTRIDE, int GSTRIDE, bool NT>
-__device__ __forceinline__ void flush_runs(const uint8_t *lds, uint32_t stage, uint8_t *g, int nvalid, int lane) {
-    using V = typename PieceT<PIECE>::type;
-    static_assert(LEN % PIECE == 0 && LSTRIDE % PIECE == 0 && GSTRIDE % PIECE == 0, "piece alignment");
-    constexpr int PPB = LEN / PIECE;
-    constexpr int TOTAL = BPW * PPB;
+// Whole-line flush after round R (aesw_layout.h flush_piece).  Lane = (block
+// lane>>3 (+8 in the second pass), 16-byte piece lane&7): 8 whole lines per
+// store instruction.  R must be a compile-time constant at the call site (the
+// round loop is fully unrolled) so every window offset folds to an immediate.
+template <class W, bool NT>
+__device__ __forceinline__ void flush_lines(const int R, const uint8_t *lds, uint32_t stage, uint8_t *g, int nvalid,
+                                            int lane) {
+    const int sub = lane & 7;
 #pragma unroll
-    for (int p0 = 0; p0 < TOTAL; p0 += LANES) {
-        const int p = p0 + lane;
-        const int blk = p / PPB;
-        const int q = p - blk * PPB;
-        if (p < TOTAL && blk < nvalid) {
-            const V v = *reinterpret_cast<const V *>(lds + stage + blk * LSTRIDE + q * PIECE);
-            gstore<NT>(reinterpret_cast<V *>(g + (size_t)blk * GSTRIDE + q * PIECE), v);
+    for (int h = 0; h < 2; ++h) {
+        const int b = (lane >> 3) + 8 * h;
+#pragma unroll
+        for (int t = 0; t < flush_maxc<W>(R); ++t) {
+            const FlushPiece fp = flush_piece<W>(R, b, sub, t, nvalid);
+            if (fp.ok) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + stage + fp.lds_off);
+                gstore<NT>(reinterpret_cast<u32x4 *>(g + fp.P), v);
+            }
         }
     }
 }
@@ -144,7 +147,10 @@ __device__ __forceinline__ void flush_contig(const uint8_t *lds, uint32_t stage,
 // ---------------------------------------------------------------------------
 template <int L>
 struct Stage {
-    static constexpr int SX = SegX<L>::STRIDE, SY = SegY<L>::STRIDE, SZ = SegZ<L>::STRIDE;
+    using WX = WinX<L>;
+    using WY = WinY<L>;
+    using WZ = WinZ<L>;
+    static constexpr int SX = WX::BYTES, SY = WY::BYTES, SZ = WZ::BYTES;  // window bytes per block
     static constexpr int OX = 0, OY = BPW * SX, OZ = OY + BPW * SY;
     static constexpr int ENC_BYTES = OZ + BPW * SZ;
     using G = Geo<L>;
@@ -223,8 +229,8 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     const int blk = lane >> 2, w = lane & 3;
 
     // tables -> LDS
-    if (tid < TAB_BYTES / 4)
-        reinterpret_cast<uint32_t *>(lds)[tid] = reinterpret_cast<const uint32_t *>(a.tables)[tid];
+    for (int i = tid; i < TAB_BYTES / 4; i += blockDim.x)  // groups may be as small as one wave
+        reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(a.tables)[i];
     __syncthreads();
     const Tables<XT> tab{lds};
 
@@ -287,36 +293,26 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
         return emit_mix_ark<L>(s, relx, rely, relz, sh, rkw, tab);
     };
 
-    // segment 0: rows 0..31 and round 1
+    // rows 0..31, then rounds 1..9 (+10); after each round the lines that just
+    // became complete are flushed.  Fully unrolled: R is a constant in every copy.
+    using WX = typename St::WX;
+    using WY = typename St::WY;
+    using WZ = typename St::WZ;
     uint32_t st = emit_head<L>(s, ptw, rkp[0]);
-    st = round(G::X_HEAD, G::Y_HEAD, G::Z_HEAD, st, rkp[4]);
-    wave_lds_fence();
-    flush_runs<16, SegX<L>::len(0), St::SX, G::XS, NT>(lds, stage + St::OX, gx, nvalid, lane);
-    flush_runs<16, SegY<L>::len(0), St::SY, G::YS, NT>(lds, stage + St::OY, gy, nvalid, lane);
-    flush_runs<16, SegZ<L>::len(0), St::SZ, G::ZS, NT>(lds, stage + St::OZ, gz, nvalid, lane);
-    wave_lds_fence();
-
-    // segments 1..7: rounds 2..8
-    for (int g = 1; g <= 7; ++g) {
-        st = round(0, 0, 0, st, rkp[4 * (g + 1)]);
+#pragma unroll
+    for (int R = 1; R <= 9; ++R) {
+        st = round(WX::woff(R), WY::woff(R), WZ::woff(R), st, rkp[4 * R]);
+        if (R == 9) {
+            const uint32_t sub = emit_sbox<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), st, tab);
+            const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
+            st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkp[40]);
+        }
         wave_lds_fence();
-        flush_runs<16, SegX<L>::len(1), St::SX, G::XS, NT>(lds, stage + St::OX, gx + SegX<L>::start(g), nvalid, lane);
-        flush_runs<16, SegY<L>::len(1), St::SY, G::YS, NT>(lds, stage + St::OY, gy + SegY<L>::start(g), nvalid, lane);
-        flush_runs<16, SegZ<L>::len(1), St::SZ, G::ZS, NT>(lds, stage + St::OZ, gz + SegZ<L>::start(g), nvalid, lane);
+        flush_lines<WX, NT>(R, lds, stage + St::OX, gx, nvalid, lane);
+        flush_lines<WY, NT>(R, lds, stage + St::OY, gy, nvalid, lane);
+        flush_lines<WZ, NT>(R, lds, stage + St::OZ, gz, nvalid, lane);
         wave_lds_fence();
     }
-
-    // segment 8: round 9 and round 10
-    st = round(0, 0, 0, st, rkp[36]);
-    {
-        const uint32_t sub = emit_sbox<L>(s, G::X_ROUND, G::Y_ROUND, G::Z_ROUND, st, tab);
-        const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
-        st = emit_final_ark<L>(s, G::X_ROUND, G::Y_ROUND, G::Z_ROUND, sh, rkp[40]);
-    }
-    wave_lds_fence();
-    flush_runs<16, SegX<L>::len(8), St::SX, G::XS, NT>(lds, stage + St::OX, gx + SegX<L>::start(8), nvalid, lane);
-    flush_runs<16, SegY<L>::len(8), St::SY, G::YS, NT>(lds, stage + St::OY, gy + SegY<L>::start(8), nvalid, lane);
-    flush_runs<16, SegZ<L>::len(8), St::SZ, G::ZS, NT>(lds, stage + St::OZ, gz + SegZ<L>::start(8), nvalid, lane);
 
     if (a.ct && live) reinterpret_cast<uint32_t *>(a.ct)[(blk0 + blk) * 4 + w] = st;
 }
@@ -332,8 +328,8 @@ __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
     const int blk = lane >> 2, w = lane & 3;
-    if (tid < TAB_BYTES / 4)
-        reinterpret_cast<uint32_t *>(lds)[tid] = reinterpret_cast<const uint32_t *>(a.tables)[tid];
+    for (int i = tid; i < TAB_BYTES / 4; i += blockDim.x)  // groups may be as small as one wave
+        reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(a.tables)[i];
     __syncthreads();
     const Tables<XT> tab{lds};
     const uint32_t stage = TAB_BYTES + wave * WAVE_LDS;

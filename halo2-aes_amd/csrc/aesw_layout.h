@@ -64,19 +64,86 @@ struct Geo {
     static constexpr int KZ_SHIFT = L == DENSE ? 0 : 4;
 };
 
-// Flush segments: the encrypt slab leaves LDS in 9 pieces per column --
-// segment 0 = head + round 1, segments 1..7 = rounds 2..8, segment 8 = round 9
-// + round 10 -- so every piece is a multiple of 16 bytes in both layouts.
-constexpr int N_SEG = 9;
-template <int HEAD, int ROUND, int TAIL>
-struct Seg {
-    static constexpr int STRIDE = ROUND + (HEAD > TAIL ? HEAD : TAIL);  // LDS bytes per block
-    AESW_HD static constexpr int start(int g) { return g == 0 ? 0 : HEAD + ROUND * g; }
-    AESW_HD static constexpr int len(int g) { return ROUND + (g == 0 ? HEAD : 0) + (g == N_SEG - 1 ? TAIL : 0); }
+// LDS staging window of one block, one column (DESIGN.md "staging window").
+// HBM wants whole 128-byte lines: per-round runs (144/112/64 B at 16-byte
+// alignment) write every line two or three times partially and cap at ~3 TB/s,
+// whole lines reach ~5.5 TB/s (tools/storebench.hip).  So after every round a
+// wave flushes only the lines that are complete; the <=112 not yet flushed
+// bytes of a block stay in LDS.  Window layout (bytes, block-relative offset o):
+//   [0, PERM_END)            head + the first PERM_R rounds, kept until the end:
+//                            the first (<128) bytes of a block share a line with
+//                            the previous block's tail, which completes last
+//   NSLOT slots of ROUND     rounds PERM_R+1..9, slot = (R-PERM_R-1) % NSLOT
+//   TAIL                     round 10
+// padded to BYTES = 16 (mod 32) so that the same offset of the 8 blocks of a
+// half-wave falls on 8 different 4-bank groups (conflict-free ds_write_b32).
+template <int HEAD_, int ROUND_, int TAIL_, int GSTRIDE_>
+struct Win {
+    static constexpr int HEAD = HEAD_, ROUND = ROUND_, TAIL = TAIL_, GSTRIDE = GSTRIDE_;
+    static constexpr int PERM_R = HEAD + ROUND >= 128 ? 1 : (HEAD + 2 * ROUND >= 128 ? 2 : 3);
+    static constexpr int NSLOT = 1 + (112 + ROUND - 1) / ROUND;  // rounds that can hold unflushed bytes, +1 being written
+    static constexpr int PERM_END = HEAD + PERM_R * ROUND;
+    static constexpr int SLOT0 = PERM_END;
+    static constexpr int TAIL0 = SLOT0 + NSLOT * ROUND;
+    static constexpr int RAW = TAIL0 + TAIL;
+    static constexpr int BYTES = RAW + ((16 - RAW % 32) + 32) % 32;
+    static_assert(HEAD + 9 * ROUND + TAIL == GSTRIDE, "column geometry");
+    static_assert(HEAD % 16 == 0 && ROUND % 16 == 0 && TAIL % 16 == 0 && GSTRIDE % 16 == 0, "16-byte pieces");
+    static_assert((16 * GSTRIDE) % 128 == 0, "a wave's 16-block range is line aligned");
+    // block-relative offset where round R starts (R = 10: the tail) / ends
+    AESW_HD static constexpr int start(int R) { return HEAD + ROUND * (R - 1); }
+    AESW_HD static constexpr int end(int R) { return R >= 10 ? GSTRIDE : HEAD + ROUND * R; }
+    // window offset where round R's bytes are staged
+    AESW_HD static constexpr int woff(int R) {
+        return R <= PERM_R ? start(R) : (R >= 10 ? TAIL0 : SLOT0 + ((R - PERM_R - 1) % NSLOT) * ROUND);
+    }
 };
-template <int L> using SegX = Seg<Geo<L>::X_HEAD, Geo<L>::X_ROUND, Geo<L>::X_TAIL>;
-template <int L> using SegY = Seg<Geo<L>::Y_HEAD, Geo<L>::Y_ROUND, Geo<L>::Y_TAIL>;
-template <int L> using SegZ = Seg<Geo<L>::Z_HEAD, Geo<L>::Z_ROUND, Geo<L>::Z_TAIL>;
+template <int L> using WinX = Win<Geo<L>::X_HEAD, Geo<L>::X_ROUND, Geo<L>::X_TAIL, Geo<L>::XS>;
+template <int L> using WinY = Win<Geo<L>::Y_HEAD, Geo<L>::Y_ROUND, Geo<L>::Y_TAIL, Geo<L>::YS>;
+template <int L> using WinZ = Win<Geo<L>::Z_HEAD, Geo<L>::Z_ROUND, Geo<L>::Z_TAIL, Geo<L>::ZS>;
+
+// Whole-line flush after round R (1..9; flush 9 also carries round 10).
+// For block b of a wave (column bytes [b*GSTRIDE, (b+1)*GSTRIDE) of the wave's
+// line-aligned 16-block range) the lines that just became complete are
+// [lo, hi); piece (t, sub) is 16 bytes of line lo+t.  Returns where the piece
+// sits in the wave's LDS column stage (block windows of W::BYTES) and where it
+// goes in the wave's global range.  Shared by the kernel and the CPU lane model.
+struct FlushPiece {
+    bool ok;
+    int lds_off;  // relative to the wave's stage of this column
+    int P;        // byte offset in the wave's 16-block column range
+};
+
+template <class W>
+AESW_HD constexpr int flush_maxc(int R) {
+    return ((R == 1 ? W::end(1) : W::end(R == 9 ? 10 : R) - W::end(R - 1)) + 127) / 128 + (R == 9 ? 1 : 0);
+}
+
+template <class W>
+AESW_HD FlushPiece flush_piece(int R, int b, int sub, int t, int nvalid) {
+    const int rmin = R - (W::NSLOT - 1) < 1 ? 1 : R - (W::NSLOT - 1);
+    const int base = b * W::GSTRIDE;
+    const int lo = R == 1 ? (base + 127) >> 7 : (base + W::end(R - 1)) >> 7;
+    const int hi = R == 9 ? (base + W::GSTRIDE + 127) >> 7 : (base + W::end(R)) >> 7;
+    const int k = lo + t;
+    const int P = 128 * k + 16 * sub;
+    int o = P - base;  // block-relative offset of this piece
+    bool ok = k < hi && b < nvalid;
+    int a = b * W::BYTES;
+    int adj = W::woff(rmin) - W::start(rmin);  // window offset = o + adj
+    for (int r = rmin + 1; r <= R; ++r) adj = o >= W::start(r) ? W::woff(r) - W::start(r) : adj;
+    if (R == 9) {
+        adj = o >= W::start(10) ? W::woff(10) - W::start(10) : adj;
+        if (o >= W::GSTRIDE) {
+            // the tail of this line is the next block's head, which its window kept
+            ok = ok && b + 1 < nvalid;
+            a += W::BYTES;
+            o -= W::GSTRIDE;
+            adj = 0;
+        }
+    }
+    return FlushPiece{ok, a + o + adj, P};
+}
 
 // MixColumns matrix rows as the reference writes them (src/aes128.rs:228-233).
 constexpr int MIX[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};

@@ -1,11 +1,12 @@
-// lane_model.cpp -- CPU execution of the per-lane code in
-// halo2-aes_amd/csrc/aesw_lane.h (the same source the HIP kernels compile),
-// with the cross-lane steps (DPP quad permutes, LDS staging) replaced by plain
-// arrays.  TEST INFRASTRUCTURE: lets `-m "not gpu"` tests compare the lane
-// program (perm selectors, slab offsets) with the oracle before any GPU run.
-// It is not reachable from the product library.
+// lane_model.cpp -- CPU execution of the device program's shared source:
+// the per-lane code (halo2-aes_amd/csrc/aesw_lane.h), the staging windows and
+// the whole-line flush index math (aesw_layout.h), wave by wave (16 blocks),
+// with the cross-lane steps (DPP quad permutes) and LDS replaced by arrays.
+// TEST INFRASTRUCTURE: lets `-m "not gpu"` tests compare the device program
+// with the oracle before any GPU run.  Not reachable from the product library.
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "../../halo2-aes_amd/csrc/aesw_lane.h"
 
@@ -13,15 +14,17 @@ using namespace aesw;
 
 namespace {
 
+constexpr int BPW = 16;
+
 template <int L>
-struct HostSink {
-    uint8_t *col[3];  // block base + segment start, per column
+struct WinSink {  // writes into the block's three staging windows, like DevSink
+    uint8_t *win[3];
     int w;
     static void put(uint8_t *p, uint32_t v) { std::memcpy(p, &v, 4); }
-    template <int C> void plain(int off, uint32_t v) { put(col[C] + off + 4 * w, v); }
+    template <int C> void plain(int off, uint32_t v) { put(win[C] + off + 4 * w, v); }
     template <int C> void mix(int off, int k, uint32_t v) {
         constexpr int mw = C == 0 ? Geo<L>::X_MIXW : C == 1 ? Geo<L>::Y_MIXW : Geo<L>::Z_MIXW;
-        put(col[C] + off + mw * w + 4 * k, v);
+        put(win[C] + off + mw * w + 4 * k, v);
     }
 };
 
@@ -36,55 +39,83 @@ struct HostKSink {
 
 uint32_t ld32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 
+template <class W>
+void flush_col(int R, const std::vector<uint8_t> &stage, uint8_t *g, int nvalid) {
+    for (int lane = 0; lane < 64; ++lane)
+        for (int h = 0; h < 2; ++h)
+            for (int t = 0; t < flush_maxc<W>(R); ++t) {
+                const FlushPiece fp = flush_piece<W>(R, (lane >> 3) + 8 * h, lane & 7, t, nvalid);
+                if (fp.ok) std::memcpy(g + fp.P, stage.data() + fp.lds_off, 16);
+            }
+}
+
 template <int L, bool XT>
 void run(const uint8_t *tab, const uint8_t *pt, const uint8_t *keys, int per_block_keys, int key_only, uint64_t n,
          uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct, uint8_t *wd, uint8_t *kx, uint8_t *ky, uint8_t *kz,
          uint8_t *rk_out) {
     using G = Geo<L>;
+    using WX = WinX<L>;
+    using WY = WinY<L>;
+    using WZ = WinZ<L>;
     Tables<XT> T{tab};
-    uint32_t rk[11][4];
-    bool have = false;
-    for (uint64_t b = 0; b < n; ++b) {
-        if (per_block_keys || key_only || !have) {
-            const uint8_t *key = keys + ((per_block_keys || key_only) ? 16 * b : 0);
-            const bool emit = per_block_keys || key_only;
-            for (int w = 0; w < 4; ++w) rk[0][w] = ld32(key + 4 * w);
-            HostKSink ks{emit && kx ? kx + (size_t)G::KXS * b : nullptr, emit && ky ? ky + (size_t)G::KYS * b : nullptr,
-                         emit && kz ? kz + (size_t)G::KZS * b : nullptr, emit && wd ? wd + (size_t)WORDS_ROWS * b : nullptr};
-            for (int w = 0; w < 4; ++w) ks.words(4 * w, rk[0][w]);
+    std::vector<uint32_t> rk((size_t)BPW * 44);
+    bool have_shared = false;
+    uint32_t rks[44];
+    for (uint64_t blk0 = 0; blk0 < n; blk0 += BPW) {
+        const int nvalid = n - blk0 >= (uint64_t)BPW ? BPW : (int)(n - blk0);
+        // ---- key phase
+        for (int b = 0; b < BPW; ++b) {
+            const bool live = b < nvalid;
+            const bool own_key = per_block_keys || key_only;
+            if (!own_key && have_shared) { std::memcpy(&rk[b * 44], rks, sizeof rks); continue; }
+            uint8_t zero[16] = {0};
+            const uint8_t *key = own_key ? (live ? keys + 16 * (blk0 + b) : zero) : keys;
+            const bool emit = own_key && live;
+            uint32_t *r = &rk[b * 44];
+            for (int w = 0; w < 4; ++w) r[w] = ld32(key + 4 * w);
+            const uint64_t gb = blk0 + b;
+            HostKSink ks{emit && kx ? kx + (size_t)G::KXS * gb : nullptr, emit && ky ? ky + (size_t)G::KYS * gb : nullptr,
+                         emit && kz ? kz + (size_t)G::KZS * gb : nullptr, emit && wd ? wd + (size_t)WORDS_ROWS * gb : nullptr};
+            for (int w = 0; w < 4; ++w) ks.words(4 * w, r[w]);
             for (int rho = 1; rho <= 10; ++rho)
                 for (int w = 0; w < 4; ++w)
-                    rk[rho][w] = emit_key_round<L>(ks, rho, w, rk[rho - 1][0], rk[rho - 1][1], rk[rho - 1][2],
-                                                   rk[rho - 1][3], rcon(rho - 1), T);
-            if (emit && rk_out) std::memcpy(rk_out + (size_t)RK_BYTES * b, rk, RK_BYTES);
-            have = true;
+                    r[4 * rho + w] = emit_key_round<L>(ks, rho, w, r[4 * rho - 4], r[4 * rho - 3], r[4 * rho - 2],
+                                                       r[4 * rho - 1], rcon(rho - 1), T);
+            if (emit && rk_out) std::memcpy(rk_out + (size_t)RK_BYTES * gb, r, RK_BYTES);
+            if (!own_key) { std::memcpy(rks, r, sizeof rks); have_shared = true; }
         }
         if (key_only) continue;
-        uint8_t *bx = x + (size_t)G::XS * b, *by = y + (size_t)G::YS * b, *bz = z + (size_t)G::ZS * b;
-        uint32_t st[4], sub[4], sh[4];
-        auto sink = [&](int g, int w) {
-            return HostSink<L>{{bx + SegX<L>::start(g), by + SegY<L>::start(g), bz + SegZ<L>::start(g)}, w};
+        // ---- encrypt phase: one wave = 16 block windows per column
+        std::vector<uint8_t> sx((size_t)BPW * WX::BYTES, 0xEE), sy((size_t)BPW * WY::BYTES, 0xEE), sz((size_t)BPW * WZ::BYTES, 0xEE);
+        uint32_t st[BPW][4], sub[4], sh[4];
+        auto sink = [&](int b, int w) {
+            return WinSink<L>{{sx.data() + b * WX::BYTES, sy.data() + b * WY::BYTES, sz.data() + b * WZ::BYTES}, w};
         };
-        for (int w = 0; w < 4; ++w) {
-            auto s = sink(0, w);
-            st[w] = emit_head<L>(s, ld32(pt + 16 * b + 4 * w), rk[0][w]);
-        }
-        for (int R = 1; R <= 9; ++R) {
-            const int g = R - 1;  // segment of this round (round 9 lives in segment 8)
-            const int rx = g == 0 ? G::X_HEAD : 0, ry = g == 0 ? G::Y_HEAD : 0, rz = g == 0 ? G::Z_HEAD : 0;
-            for (int w = 0; w < 4; ++w) { auto s = sink(g, w); sub[w] = emit_sbox<L>(s, rx, ry, rz, st[w], T); }
-            for (int w = 0; w < 4; ++w) sh[w] = shift_rows(sub[w], sub[(w + 1) & 3], sub[(w + 2) & 3], sub[(w + 3) & 3]);
-            for (int w = 0; w < 4; ++w) { auto s = sink(g, w); st[w] = emit_mix_ark<L>(s, rx, ry, rz, sh[w], rk[R][w], T); }
-        }
-        {
-            const int g = 8, rx = G::X_ROUND, ry = G::Y_ROUND, rz = G::Z_ROUND;
-            for (int w = 0; w < 4; ++w) { auto s = sink(g, w); sub[w] = emit_sbox<L>(s, rx, ry, rz, st[w], T); }
-            for (int w = 0; w < 4; ++w) sh[w] = shift_rows(sub[w], sub[(w + 1) & 3], sub[(w + 2) & 3], sub[(w + 3) & 3]);
+        for (int b = 0; b < BPW; ++b)
             for (int w = 0; w < 4; ++w) {
-                auto s = sink(g, w);
-                const uint32_t c = emit_final_ark<L>(s, rx, ry, rz, sh[w], rk[10][w]);
-                if (ct) std::memcpy(ct + 16 * b + 4 * w, &c, 4);
+                auto s = sink(b, w);
+                const uint32_t ptw = b < nvalid ? ld32(pt + 16 * (blk0 + b) + 4 * w) : 0u;
+                st[b][w] = emit_head<L>(s, ptw, rk[b * 44 + w]);
             }
+        uint8_t *gx = x + (size_t)G::XS * blk0, *gy = y + (size_t)G::YS * blk0, *gz = z + (size_t)G::ZS * blk0;
+        for (int R = 1; R <= 9; ++R) {
+            for (int b = 0; b < BPW; ++b) {
+                for (int w = 0; w < 4; ++w) { auto s = sink(b, w); sub[w] = emit_sbox<L>(s, WX::woff(R), WY::woff(R), WZ::woff(R), st[b][w], T); }
+                for (int w = 0; w < 4; ++w) sh[w] = shift_rows(sub[w], sub[(w + 1) & 3], sub[(w + 2) & 3], sub[(w + 3) & 3]);
+                for (int w = 0; w < 4; ++w) { auto s = sink(b, w); st[b][w] = emit_mix_ark<L>(s, WX::woff(R), WY::woff(R), WZ::woff(R), sh[w], rk[b * 44 + 4 * R + w], T); }
+                if (R == 9) {
+                    for (int w = 0; w < 4; ++w) { auto s = sink(b, w); sub[w] = emit_sbox<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), st[b][w], T); }
+                    for (int w = 0; w < 4; ++w) sh[w] = shift_rows(sub[w], sub[(w + 1) & 3], sub[(w + 2) & 3], sub[(w + 3) & 3]);
+                    for (int w = 0; w < 4; ++w) {
+                        auto s = sink(b, w);
+                        st[b][w] = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh[w], rk[b * 44 + 40 + w]);
+                        if (ct && b < nvalid) std::memcpy(ct + 16 * (blk0 + b) + 4 * w, &st[b][w], 4);
+                    }
+                }
+            }
+            flush_col<WX>(R, sx, gx, nvalid);
+            flush_col<WY>(R, sy, gy, nvalid);
+            flush_col<WZ>(R, sz, gz, nvalid);
         }
     }
 }
@@ -105,4 +136,14 @@ extern "C" int lane_model_run(const uint8_t *tab768, const uint8_t *pt, const ui
 extern "C" void lane_model_masks(int col, uint8_t *enc_mask, uint8_t *key_mask) {
     encrypt_assigned_mask(col, enc_mask);
     key_assigned_mask(col, key_mask);
+}
+
+// window geometry, for the tests
+extern "C" void lane_model_window(int layout, int col, int out[6]) {
+    auto fill = [&](auto w) {
+        using W = decltype(w);
+        out[0] = W::PERM_R; out[1] = W::NSLOT; out[2] = W::PERM_END; out[3] = W::TAIL0; out[4] = W::RAW; out[5] = W::BYTES;
+    };
+    if (layout == DENSE) { if (col == 0) fill(WinX<DENSE>{}); else if (col == 1) fill(WinY<DENSE>{}); else fill(WinZ<DENSE>{}); }
+    else { if (col == 0) fill(WinX<PACKED>{}); else if (col == 1) fill(WinY<PACKED>{}); else fill(WinZ<PACKED>{}); }
 }
