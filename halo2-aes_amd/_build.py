@@ -1,11 +1,10 @@
-"""Builds the in-tree native artefacts.
+"""Builds the product library in-tree.
 
-  halo2-aes_amd/libaesw.so          the product: HIP kernels + C ABI (hipcc, gfx950)
-  oracle/libaesw_oracle.so          test infrastructure: CPU oracle (gcc)
-  tests/lane_model/liblane_model.so test infrastructure: CPU run of aesw_lane.h (g++)
+  halo2-aes_amd/libaesw.so   HIP kernels + C ABI (hipcc --offload-arch=gfx950)
 
-hipcc cross-compiles gfx950 code objects without a GPU.  The .so files are
-git-ignored but travel to the GPU box with the snapshot.
+hipcc cross-compiles gfx950 code objects without a GPU.  The .so is git-ignored
+but travels to the GPU box with the snapshot.  (The test-only artefacts are
+built by __graft_entry__.build(), not from inside the product package.)
 """
 from __future__ import annotations
 
@@ -18,8 +17,6 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libaesw.so"
-ORACLE_LIB = ROOT / "oracle" / "libaesw_oracle.so"
-LANE_LIB = ROOT / "tests" / "lane_model" / "liblane_model.so"
 
 
 def _newer(target: Path, sources) -> bool:
@@ -53,24 +50,3 @@ def build_product(force: bool = False) -> Path:
           "-o", str(tmp)] + [str(s) for s in srcs])
     os.replace(tmp, LIB)
     return LIB
-
-
-def build_oracle(force: bool = False) -> Path:
-    d = ROOT / "oracle"
-    if not force and _newer(ORACLE_LIB, [d / "aesw_oracle.c", d / "aesw_oracle.h"]):
-        return ORACLE_LIB
-    _run(["make", "-C", str(d), "-B", "libaesw_oracle.so"])
-    return ORACLE_LIB
-
-
-def build_lane_model(force: bool = False) -> Path:
-    src = ROOT / "tests" / "lane_model" / "lane_model.cpp"
-    deps = [src, CSRC / "aesw_lane.h", CSRC / "aesw_layout.h"]
-    if not force and _newer(LANE_LIB, deps):
-        return LANE_LIB
-    _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", str(LANE_LIB), str(src)])
-    return LANE_LIB
-
-
-def build_all(force: bool = False):
-    return build_product(force), build_oracle(force), build_lane_model(force)

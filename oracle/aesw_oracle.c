@@ -708,6 +708,12 @@ done:
 #undef FAIL
 }
 
+int aesw_o_circuit_poke(aesw_o_circuit *c, uint32_t col, uint64_t row, uint8_t value) {
+    if (!c || col >= c->n_advice || row >= c->n_rows) return AESW_O_ERR_ARG;
+    adv_col(c, col)[row] = value;
+    return AESW_O_OK;
+}
+
 /* ------------------------------------------------------------------------- */
 /* slab level                                                                 */
 /* ------------------------------------------------------------------------- */

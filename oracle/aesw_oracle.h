@@ -142,6 +142,8 @@ int aesw_o_circuit_block_placement(const aesw_o_circuit *c, uint64_t b, uint32_t
  * every queried cell is assigned.  Returns AESW_O_OK or ERR_UNSATISFIED and
  * writes a short description to msg. */
 int aesw_o_circuit_verify(const aesw_o_circuit *c, char *msg, size_t msg_len);
+/* Test hook: overwrite one advice cell (to show that verify() notices). */
+int aesw_o_circuit_poke(aesw_o_circuit *c, uint32_t col, uint64_t row, uint8_t value);
 
 #ifdef __cplusplus
 }

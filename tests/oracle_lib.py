@@ -77,6 +77,7 @@ class Oracle:
         L.aesw_o_circuit_ciphertext.argtypes = [V, U64, V]
         L.aesw_o_circuit_block_placement.argtypes = [V, U64, C.POINTER(U32), C.POINTER(U64)]
         L.aesw_o_circuit_verify.argtypes = [V, C.c_char_p, C.c_size_t]
+        L.aesw_o_circuit_poke.argtypes = [V, U32, U64, C.c_uint8]
         self.t = Tables()
         if tables is None:
             L.aesw_o_reference_tables(C.byref(self.t))
@@ -248,6 +249,9 @@ class Circuit:
         s, r = C.c_uint32(), C.c_uint64()
         assert self.L.aesw_o_circuit_block_placement(self.h, b, C.byref(s), C.byref(r)) == 0
         return int(s.value), int(r.value)
+
+    def poke(self, col, row, value):
+        assert self.L.aesw_o_circuit_poke(self.h, col, row, value) == 0
 
     def verify(self):
         buf = C.create_string_buffer(256)

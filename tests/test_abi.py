@@ -1,0 +1,104 @@
+"""The C-ABI shared library: loads, exports every symbol include/aesw.h
+declares, and its pure-host entry points behave (no compute calls: no GPU)."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared():
+    text = (ROOT / "include" / "aesw.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(aesw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    lib = pkg.load_library()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libaesw.so does not export %s" % n
+    assert sorted(pkg.api.SYMBOLS) == names, "api.py binds a different set than include/aesw.h declares"
+    out = subprocess.run(["nm", "-D", "--defined-only", str(pkg.api.LIB_PATH)], stdout=subprocess.PIPE, text=True).stdout
+    exported = set(re.findall(r" T (aesw_\w+)", out))
+    assert set(names) <= exported
+
+
+def test_library_is_gfx950_code(pkg):
+    """The product .so carries a gfx950 code object (hipcc --offload-arch=gfx950)."""
+    data = pkg.api.LIB_PATH.read_bytes()
+    assert b"gfx950" in data
+    assert b"encrypt_kernel" in data and b"key_kernel" in data
+
+
+def test_version_and_strerror(pkg):
+    lib = pkg.load_library()
+    assert lib.aesw_version() == 100
+    assert lib.aesw_strerror(0) == b"ok"
+    assert b"AES calls too many" in lib.aesw_strerror(5)   # the reference's panic text, src/aes128.rs:161
+    assert b"Keys should be scheduled" in lib.aesw_strerror(6)  # src/aes128.rs:170
+    assert lib.aesw_strerror(12345) == b"unknown status"
+
+
+def test_geometry(pkg, oracle):
+    assert [pkg.column_stride(pkg.LAYOUT_DENSE, c) for c in range(3)] == [1360, 1360, 1360]
+    assert [pkg.column_stride(pkg.LAYOUT_PACKED, c) for c in range(3)] == [1360, 1056, 608]
+    assert [pkg.key_column_stride(pkg.LAYOUT_DENSE, c) for c in range(3)] == [400, 400, 400]
+    assert [pkg.key_column_stride(pkg.LAYOUT_PACKED, c) for c in range(3)] == [400, 240, 200]
+    assert pkg.column_stride(7, 0) == 0 and pkg.column_stride(0, 3) == 0
+    for c in range(3):
+        assert np.array_equal(pkg.packed_index(c), oracle.packed_index(c))
+        assert np.array_equal(pkg.key_packed_index(c), oracle.key_packed_index(c))
+    # algorithmic bytes per block: live cells + inputs
+    live = sum(pkg.column_stride(pkg.LAYOUT_PACKED, c) for c in range(3))
+    klive = 96 + sum(pkg.key_column_stride(pkg.LAYOUT_PACKED, c) for c in range(3))
+    assert live + 16 == 3040 and live + klive + 32 == 3992
+
+
+def test_block_placement_mirrors_aes_callable(pkg, oracle):
+    """aesw_block_placement == where the oracle's restated aes_callable() puts blocks."""
+    assert pkg.block_capacity(20, 5) == 769 + 4 * 771 == 3853
+    assert pkg.block_capacity(20, 4) == 3082 and pkg.block_capacity(20, 3) == 2311
+    assert pkg.block_placement(20, 3, 0) == (0, 400)
+    assert pkg.block_placement(20, 3, 768) == (0, 400 + 768 * 1360)
+    assert pkg.block_placement(20, 3, 769) == (1, 0)
+    with pytest.raises(pkg.AeswError) as e:
+        pkg.block_placement(20, 5, 3853)           # the reference panics here (benches/aes128.rs asks for 6000)
+    assert e.value.status == 5
+    pts = np.zeros((120, 16), np.uint8)
+    with oracle.circuit(16, 3, np.zeros(16, np.uint8), pts, record_copies=False) as c:
+        for b in range(120):
+            assert c.block_placement(b) == pkg.block_placement(16, 3, b)
+    assert pkg.block_capacity(10, 2) == 0          # 2^10 < 1760: set 0 holds nothing, set 1 holds 0 (1024 < 1360)
+
+
+def test_no_cpu_path(pkg):
+    """Without a gfx950 device the library refuses to create a context."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.AeswError) as e:
+        pkg.Context(0)
+    assert e.value.status == 2
+    assert pkg.device_count() == 0
+
+
+def test_missing_library_fails_loudly(pkg, tmp_path):
+    with pytest.raises(FileNotFoundError):
+        pkg.api.load_library(tmp_path / "libaesw.so")
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under halo2-aes_amd/ or include/ may reference oracle/ or the lane model (test infrastructure)."""
+    for p in list((ROOT / "halo2-aes_amd").rglob("*")) + list((ROOT / "include").rglob("*")):
+        if p.is_file() and p.suffix in (".py", ".h", ".hip", ".cpp", ".hpp"):
+            text = p.read_text()
+            for word in ("aesw_oracle", "oracle_lib", "libaesw_oracle", "liblane_model", "oracle/"):
+                assert word not in text, "%s mentions %s" % (p, word)

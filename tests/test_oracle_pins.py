@@ -1,0 +1,224 @@
+"""Pins the CPU oracle to everything the reference's own files hold for this
+path: constant.rs tables, the xor KAT, the EXPANDED zero-key
+round keys, AES_ROWS / KEY_SCHEDULE_ROWS, MockProver-style satisfaction of the
+reference's two integration tests, the capacity panic, and FIPS-197 KATs that
+are valid for the reference's (non-FIPS) S-box."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import slab_map
+
+GOLD = Path(__file__).resolve().parent / "golden"
+REF = Path("/root/reference")
+
+
+@pytest.fixture(scope="module")
+def consts():
+    return json.loads((GOLD / "reference_constants.json").read_text())
+
+
+def test_tables_match_reference_constants(oracle, consts):
+    sbox, mul2, mul3 = oracle.tables()
+    assert sbox.tolist() == consts["S_BOX"]          # src/constant.rs:1-15
+    assert mul2.tolist() == consts["MUL_BY_2"]       # :17-31
+    assert mul3.tolist() == consts["MUL_BY_3"]       # :33-47
+    assert consts["S_BOX"][255] == 23                # the reference's non-FIPS entry (FIPS-197: 22)
+    fs, f2, f3 = oracle.fips_tables()
+    assert fs[255] == 22 and np.array_equal(fs[:255], sbox[:255])
+    assert sorted(fs.tolist()) == list(range(256))   # FIPS S-box is a permutation, the reference's is not
+    assert sorted(sbox.tolist()) != list(range(256))
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference tree only exists in the build container")
+def test_fixture_still_matches_reference_text(consts):
+    src = (REF / "src" / "constant.rs").read_text()
+    for name in ("S_BOX", "MUL_BY_2", "MUL_BY_3"):
+        m = re.search(r"pub const %s: \[u8; 256\] = \[(.*?)\];" % name, src, re.S)
+        assert [int(v) for v in m.group(1).replace("\n", " ").split(",") if v.strip()] == consts[name]
+
+
+def test_product_host_constants_match_reference(pkg, consts):
+    sbox, mul2, mul3 = pkg.reference_tables()
+    assert sbox.tolist() == consts["S_BOX"] and mul2.tolist() == consts["MUL_BY_2"] and mul3.tolist() == consts["MUL_BY_3"]
+    assert pkg.AES_ROWS == consts["AES_ROWS"] and pkg.KEY_SCHEDULE_ROWS == consts["KEY_SCHEDULE_ROWS"]
+    assert list(pkg.constants.ROUND_CONSTANT) == consts["ROUND_CONSTANT"]
+
+
+def test_xor_bytes_kat(oracle, consts):
+    k = consts["xor_kat"]                             # src/utils.rs:40-47: 5 ^ 12 == 9
+    assert oracle.xor_bytes(k["x"], k["y"]) == k["z"]
+    for x in range(0, 256, 17):
+        for y in range(0, 256, 13):
+            assert oracle.xor_bytes(x, y) == x ^ y
+
+
+def test_round_constants(oracle, consts):
+    assert [oracle.L.aesw_o_round_constant(i) for i in range(10)] == consts["ROUND_CONSTANT"]
+
+
+def test_expanded_zero_key(oracle, consts):
+    """src/key_schedule.rs:337-345 EXPANDED (the #[ignore]d test's values are valid)."""
+    kw = oracle.key_schedule_witness(np.zeros(16, np.uint8), layout=ol.DENSE)
+    words = [kw.rk[0, 4 * i:4 * i + 4].tobytes().hex() for i in range(44)]
+    assert words == consts["EXPANDED_ZERO_KEY"]
+
+
+def test_row_counts(oracle, consts):
+    assert consts["AES_ROWS"] == ol.AES_ROWS == 1360
+    assert [int(oracle.assigned_mask(c).sum()) for c in range(3)] == [1360, 1056, 608]
+    assert [int(oracle.key_assigned_mask(c).sum()) for c in range(3)] == [400, 240, 200]
+    with oracle.circuit(12, 1, np.zeros(16, np.uint8), np.zeros((1, 16), np.uint8)) as c:
+        assert c.status == 0
+        assert c.column_height(3) == 96            # words_column
+        assert c.column_height(0) == 400 + 1360    # key rows then one block
+        assert c.num_regions == 21 + 400 + 1360 - 15  # key: 1+10*(2+40); block: 1 (16-row) + 1344 one-row regions
+        assert c.block_placement(0) == (0, 400)
+
+
+def test_test_correct_encryption_mockprover(oracle):
+    """src/aes128.rs:409-418: K=20, N=3, 1000 encryptions of the zero block under the zero key."""
+    with oracle.circuit(20, 3, np.zeros(16, np.uint8), np.zeros((1000, 16), np.uint8)) as c:
+        assert c.status == 0
+        rc, msg = c.verify()
+        assert rc == 0, msg
+        assert c.ciphertext(0).tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
+        assert c.ciphertext(999).tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
+        assert c.block_placement(768) == (0, 400 + 768 * 1360)
+        assert c.block_placement(769) == (1, 0)    # set 0 holds 769 blocks at K=20 (src/aes128.rs:303-325)
+        # a wrong witness byte is noticed (lookup or copy constraint)
+        _, row = c.block_placement(5)
+        c.poke(2, row + 20, int(c.advice(2)[row + 20]) ^ 1)
+        rc, msg = c.verify()
+        assert rc != 0 and msg
+
+
+def test_test_constraints_key_schedule_mockprover(oracle):
+    """src/key_schedule.rs:385-392: K=17, zero key."""
+    with oracle.key_circuit(17, np.zeros(16, np.uint8)) as c:
+        assert c.status == 0
+        rc, msg = c.verify()
+        assert rc == 0, msg
+        assert c.column_height(0) == 400 and c.column_height(3) == 96
+        c.poke(3, 20, 7)                           # break the rcon gate / a copy
+        assert c.verify()[0] != 0
+
+
+def test_random_inputs_satisfy_constraints(oracle):
+    rng = np.random.default_rng(11)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (50, 16), dtype=np.uint8)
+    pts[3] = key ^ 0xFF                            # first S-box input 0xff everywhere
+    with oracle.circuit(16, 2, key, pts) as c:
+        assert c.status == 0
+        rc, msg = c.verify()
+        assert rc == 0, msg
+        # 2^16 rows: set 0 holds (65536-1760)//1360 = 46 blocks, so block 46 switches to set 1
+        assert c.block_placement(45)[0] == 0 and c.block_placement(46) == (1, 0)
+
+
+def test_capacity_panic(oracle):
+    """benches/aes128.rs asks for 6000 blocks in FixedAes128Config<20,5>; capacity is
+    769 + 4*771 = 3853, so the reference panics at src/aes128.rs:160-162."""
+    with oracle.circuit(20, 5, np.zeros(16, np.uint8), np.zeros((3854, 16), np.uint8), record_copies=False) as c:
+        assert c.status == 1                       # AESW_O_ERR_CAPACITY on the 3854th call
+    with oracle.circuit(20, 5, np.zeros(16, np.uint8), np.zeros((3853, 16), np.uint8), record_copies=False) as c:
+        assert c.status == 0
+        assert c.block_placement(3852)[0] == 4
+
+
+def test_fips_kats_are_valid_for_the_reference_table(oracle):
+    cases = [("00" * 16, "00" * 16, "66e94bd4ef8a2c3b884cfa59ca342b2e"),
+             ("3243f6a8885a308d313198a2e0370734", "2b7e151628aed2a6abf7158809cf4f3c", "3925841d02dc09fbdc118597196a0b32"),
+             ("00112233445566778899aabbccddeeff", "000102030405060708090a0b0c0d0e0f", "69c4e0d86a7b0430d8cdb78070b4c55a")]
+    sbox_rows = np.concatenate([np.arange(32 + 144 * r, 48 + 144 * r) for r in range(9)] + [np.arange(1328, 1344)])
+    for p, k, c in cases:
+        pt = np.frombuffer(bytes.fromhex(p), np.uint8)
+        key = np.frombuffer(bytes.fromhex(k), np.uint8)
+        w = oracle.encrypt_witness(pt, key, layout=ol.DENSE)
+        assert w.ct.tobytes().hex() == c
+        assert not np.any(w.x[sbox_rows] == 0xFF)  # never reaches S_BOX[255]: same answer under both tables
+        kw = oracle.key_schedule_witness(key, layout=ol.DENSE)
+        key_sbox_rows = np.concatenate([np.arange(40 * r, 40 * r + 4) for r in range(10)])
+        assert not np.any(kw.kx[key_sbox_rows] == 0xFF)
+
+
+def test_reference_sbox_changes_ciphertexts(oracle):
+    """SURVEY finding 1: about 55 % of random (pt,key) pairs differ from real AES-128."""
+    rng = np.random.default_rng(2000)
+    pt = rng.integers(0, 256, (2000, 16), dtype=np.uint8)
+    keys = rng.integers(0, 256, (2000, 16), dtype=np.uint8)
+    ref = oracle.encrypt_witness(pt, keys, layout=ol.PACKED).ct
+    fips = ol.Oracle(tables=oracle.fips_tables()).encrypt_witness(pt, keys, layout=ol.PACKED).ct
+    frac = float(np.mean(np.any(ref != fips, axis=1)))
+    assert 0.45 < frac < 0.65
+
+
+def test_lookup_table(oracle, consts):
+    t = oracle.lookup_table()
+    assert t.shape == (4, 66561)
+    assert t[:, 0].tolist() == [1, 0, 0, 0] and t[:, 255].tolist() == [1, 255, 0, 0]          # Tag::U8
+    assert t[:, 256 + 255].tolist() == [3, 255, 23, 0]                                          # Tag::Sbox, the typo row
+    assert t[:, 512 + 0x12 * 256 + 0x34].tolist() == [2, 0x12, 0x34, 0x12 ^ 0x34]               # Tag::Xor
+    assert t[:, 66048 + 0x80].tolist() == [4, 0x80, 0x1B, 0]                                    # Tag::GfMul2
+    assert t[:, 66304 + 0x80].tolist() == [5, 0x80, 0x9B, 0]                                    # Tag::GfMul3
+    assert t[:, 66560].tolist() == [0, 0, 0, 0]                                                 # empty row
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_slab_map_second_opinion(oracle, seed):
+    """The numpy restatement of the slab-map table agrees with the layouter-derived oracle."""
+    rng = np.random.default_rng(seed)
+    pt = rng.integers(0, 256, 16, dtype=np.uint8)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    if seed == 3:
+        pt = key ^ 0xFF
+    sbox, mul2, mul3 = oracle.tables()
+    rk, W, kx, ky, kz, kym, kzm = slab_map.key_schedule(key, sbox)
+    x, y, z, ym, zm, ct = slab_map.encrypt_slab(pt, rk, sbox, mul2, mul3)
+    w = oracle.encrypt_witness(pt, key, layout=ol.DENSE)
+    assert np.array_equal(w.x, x) and np.array_equal(w.y, y) and np.array_equal(w.z, z) and np.array_equal(w.ct[0], ct)
+    assert np.array_equal(oracle.assigned_mask(1), ym) and np.array_equal(oracle.assigned_mask(2), zm)
+    kw = oracle.key_schedule_witness(key, layout=ol.DENSE)
+    assert kw.w.tolist() == W and kw.kx.tolist() == kx and kw.ky.tolist() == ky and kw.kz.tolist() == kz
+    assert kw.rk[0].tolist() == [v for r in rk for v in r]
+    assert oracle.key_assigned_mask(1).tolist() == kym and oracle.key_assigned_mask(2).tolist() == kzm
+    wp = oracle.encrypt_witness(pt, key, layout=ol.PACKED)
+    assert np.array_equal(wp.y, y[ym == 1]) and np.array_equal(wp.z, z[zm == 1])
+
+
+def test_circuit_slabs_equal_batched_slabs(oracle):
+    """A block's rows inside a full K/N circuit are exactly its batched slab."""
+    rng = np.random.default_rng(5)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (50, 16), dtype=np.uint8)
+    w = oracle.encrypt_witness(pts, key, layout=ol.DENSE)
+    kw = oracle.key_schedule_witness(key, layout=ol.DENSE)
+    with oracle.circuit(16, 2, key, pts) as c:
+        assert c.status == 0
+        cols = [c.advice(i) for i in range(c.num_advice)]
+        assert np.array_equal(cols[0][:400], kw.kx) and np.array_equal(cols[1][:400], kw.ky)
+        assert np.array_equal(cols[2][:400], kw.kz) and np.array_equal(cols[6][:96], kw.w)
+        for b in (0, 1, 45, 46, 49):
+            s, r = c.block_placement(b)
+            for ci, name in enumerate("xyz"):
+                assert np.array_equal(cols[3 * s + ci][r:r + 1360], getattr(w, name)[1360 * b:1360 * (b + 1)])
+            assert np.array_equal(c.ciphertext(b), w.ct[b])
+
+
+def test_golden_slab_vectors(oracle):
+    g = np.load(GOLD / "slab_vectors.npz")
+    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed")):
+        w = oracle.encrypt_witness(g["pt"], g["keys"], layout=layout)
+        k = oracle.key_schedule_witness(g["keys"], layout=layout)
+        for c in "xyz":
+            assert np.array_equal(getattr(w, c), g["%s_%s" % (name, c)])
+        assert np.array_equal(w.ct, g["%s_ct" % name])
+        for c in ("w", "kx", "ky", "kz", "rk"):
+            assert np.array_equal(getattr(k, c), g["%s_%s" % (name, c)])
+    assert g["dense_ct"][0].tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
+    assert g["dense_y"][3 * 1360 + 32] == 23   # block 3: S_BOX[0xff] as the reference has it
