@@ -55,6 +55,8 @@ SYMBOLS = {
     "aesw_key_packed_index": (_I, [_I, _P]),
     "aesw_block_placement": (_I, [_U32, _U32, _U64, C.POINTER(_U32), C.POINTER(_U64)]),
     "aesw_block_capacity": (_U64, [_U32, _U32]),
+    "aesw_schedule_key_device": (_I, [_P, _P, _I, C.POINTER(KeySlab), _P]),
+    "aesw_schedule_key": (_I, [_P, _P, _I, C.POINTER(KeySlab)]),
     "aesw_encrypt_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P]),
     "aesw_key_schedule_witness_device": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P, _P]),
     "aesw_lookup_table_device": (_I, [_P, _P, _P, _P, _P, _P]),
@@ -244,20 +246,48 @@ class Context:
         return Witness(cols[0], cols[1], cols[2], ct, key)
 
     # -- device entry points
+    def schedule_key(self, key, layout: int = K.LAYOUT_PACKED, key_slab: bool = True):
+        """FixedAes128Config::schedule_key (src/aes128.rs:143-152): expand `key`
+        (uint8[16] on the device) once; later encrypt_witness(pt, None) calls use it.
+        Returns its key-schedule witness (KeyWitness, rk=None) when key_slab."""
+        torch = self._torch()
+        key = self._u8(key, "key")
+        if key.numel() != 16:
+            raise ValueError("key must be uint8[16]")
+        out = ks = None
+        if key_slab:
+            dev = self._dev()
+            out = KeyWitness(torch.empty(K.WORDS_ROWS, dtype=torch.uint8, device=dev),
+                             *[torch.empty(key_column_stride(layout, c), dtype=torch.uint8, device=dev) for c in range(3)],
+                             None)
+            ks = KeySlab(*[t.data_ptr() for t in out[:4]])
+        rc = self._lib.aesw_schedule_key_device(self._h, key.data_ptr(), layout, C.byref(ks) if ks is not None else None,
+                                                self._stream())
+        self._check(rc, "aesw_schedule_key_device")
+        return out
+
     def encrypt_witness(self, pt, keys, layout: int = K.LAYOUT_PACKED, out: Witness | None = None,
                         want_ct: bool = False, key_slab: bool = False) -> Witness:
         """Batched FixedAes128Config::encrypt witness (src/aes128.rs:154-265).
 
-        pt: uint8[n,16] on the device.  keys: uint8[16] (shared key, the
-        reference's schedule_key once + encrypt n times) or uint8[n,16]
+        pt: uint8[n,16] on the device.  keys: None (the key given to
+        schedule_key(): the reference's schedule_key once + encrypt n times),
+        uint8[16] (one shared key expanded inside the call) or uint8[n,16]
         (per-block keys).  Asynchronous on torch's current stream.
         """
         pt = self._u8(pt, "pt")
-        keys = self._u8(keys, "keys")
         if pt.dim() != 2 or pt.shape[1] != 16:
             raise ValueError("pt must be [n,16]")
         n = pt.shape[0]
-        if keys.numel() == 16 and keys.dim() == 1:
+        if keys is None:
+            pbk = 0
+            if key_slab:
+                raise ValueError("the key slab of a scheduled key is returned by schedule_key()")
+        else:
+            keys = self._u8(keys, "keys")
+        if keys is None:
+            pass
+        elif keys.numel() == 16 and keys.dim() == 1:
             pbk = 0
         elif keys.dim() == 2 and tuple(keys.shape) == (n, 16):
             pbk = 1
@@ -273,7 +303,7 @@ class Context:
         if out.key is not None:
             ks = KeySlab(*[t.data_ptr() if t is not None else None for t in out.key[:4]])
         rc = self._lib.aesw_encrypt_witness_device(
-            self._h, pt.data_ptr(), keys.data_ptr(), pbk, n, layout, out.x.data_ptr(), out.y.data_ptr(),
+            self._h, pt.data_ptr(), keys.data_ptr() if keys is not None else None, pbk, n, layout, out.x.data_ptr(), out.y.data_ptr(),
             out.z.data_ptr(), out.ct.data_ptr() if out.ct is not None else None,
             C.byref(ks) if ks is not None else None, self._stream())
         self._check(rc, "aesw_encrypt_witness_device")

@@ -18,9 +18,11 @@ struct aesw_ctx {
     int device = -1;
     uint8_t *d_tables = nullptr;  // 768 B
     uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
+    uint8_t *d_rk = nullptr;      // 176 B: round keys of the key given to aesw_schedule_key*
+    bool have_key = false;
     bool xt = false;
-    int waves_shared = 4;  // waves per group, shared-key kernel
-    int waves_pbk = 2;     // per-block-key and key kernels
+    int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
+    int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
     bool nt = false;
     int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
     std::string last_error;
@@ -164,6 +166,7 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
     };
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), 768), "hipMalloc(tables)");
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_fr_lut), sizeof lut), "hipMalloc(fr_lut)");
+    T(hipMalloc(reinterpret_cast<void **>(&ctx->d_rk), 256), "hipMalloc(rk)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_fr_lut, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy(fr_lut)");
     if (rc != AESW_OK) {
@@ -182,6 +185,7 @@ void aesw_destroy(aesw_ctx *ctx) {
         if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
         if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
+        if (ctx->d_rk) (void)hipFree(ctx->d_rk);
     }
     delete ctx;
 }
@@ -259,8 +263,8 @@ int aesw_block_placement(uint32_t k, uint32_t n_sets, uint64_t b, uint32_t *set,
 
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return AESW_ERR_INVALID_ARG;
-    if (!std::strcmp(name, "waves_shared")) { if (value < 1 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_shared = (int)value; return AESW_OK; }
-    if (!std::strcmp(name, "waves_pbk")) { if (value < 1 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_pbk = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "waves_shared")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_shared = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "waves_pbk")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_pbk = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "nt_stores")) { ctx->nt = value != 0; return AESW_OK; }
     if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { if (value < 64) return AESW_ERR_INVALID_ARG; ctx->chunk_blocks = value; return AESW_OK; }
@@ -278,13 +282,42 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
 
 // ---- device-pointer entry points ------------------------------------------------
 
+// Waves per group when the option is 0 (auto): as many 16-block waves as keep
+// 6-8 waves resident per CU given the LDS windows (DESIGN.md "occupancy").
+static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
+    if (pbk) return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_PACKED ? 2 : 1);
+    if (ctx->waves_shared) return ctx->waves_shared;
+    return layout == AESW_LAYOUT_PACKED ? 4 : 2;
+}
+
+int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, const aesw_key_slab *ks, void *stream) {
+    if (!ctx || !valid_layout(layout) || !d_key || !aligned4(d_key)) return AESW_ERR_INVALID_ARG;
+    KeyOut ko{nullptr, nullptr, nullptr, nullptr};
+    if (ks) {
+        ko = KeyOut{ks->w, ks->kx, ks->ky, ks->kz};
+        if ((ko.w && !aligned16(ko.w)) || (ko.kx && !aligned16(ko.kx)) || (ko.ky && !aligned16(ko.ky)) ||
+            (ko.kz && !aligned16(ko.kz)))
+            return AESW_ERR_INVALID_ARG;
+    }
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    KeyParams kp{d_key, ctx->d_tables, ko, ctx->d_rk, 1};
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->nt, reinterpret_cast<hipStream_t>(stream)));
+    ctx->have_key = true;
+    return AESW_OK;
+}
+
 int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys, int per_block_keys,
                                 uint64_t n, int layout, uint8_t *d_x, uint8_t *d_y, uint8_t *d_z, uint8_t *d_ct,
                                 const aesw_key_slab *ks, void *stream) {
     if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;
+    if (!d_keys) {
+        if (per_block_keys) return AESW_ERR_INVALID_ARG;
+        if (!ctx->have_key) return AESW_ERR_NO_KEY;  // "Keys should be scheduled", src/aes128.rs:170
+    }
     if (n == 0) return AESW_OK;
-    if (!d_pt || !d_keys || !d_x || !d_y || !d_z) return AESW_ERR_INVALID_ARG;
-    if (!aligned16(d_x) || !aligned16(d_y) || !aligned16(d_z) || !aligned4(d_pt) || !aligned4(d_keys) ||
+    if (!d_pt || !d_x || !d_y || !d_z) return AESW_ERR_INVALID_ARG;
+    if (!aligned16(d_x) || !aligned16(d_y) || !aligned16(d_z) || !aligned4(d_pt) || (d_keys && !aligned4(d_keys)) ||
         (d_ct && !aligned4(d_ct)))
         return AESW_ERR_INVALID_ARG;
     KeyOut ko{nullptr, nullptr, nullptr, nullptr};
@@ -295,6 +328,7 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
             return AESW_ERR_INVALID_ARG;
     }
     const bool kemit = ko.w || ko.kx || ko.ky || ko.kz;
+    if (!d_keys && kemit) return AESW_ERR_INVALID_ARG;  // the key slab of a scheduled key comes from aesw_schedule_key*
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -303,9 +337,11 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
         KeyParams kp{d_keys, ctx->d_tables, ko, nullptr, 1};
         HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->nt, s));
     }
-    EncParams p{d_pt, d_keys, ctx->d_tables, d_x, d_y, d_z, d_ct, per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n};
-    const int waves = per_block_keys ? ctx->waves_pbk : ctx->waves_shared;
-    HIP_TRY(ctx, launch_encrypt(p, layout, ctx->xt, per_block_keys != 0, per_block_keys && kemit, waves, ctx->nt, s));
+    const int km = per_block_keys ? 0 : (d_keys ? 1 : 2);
+    EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, d_x, d_y, d_z, d_ct,
+                per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n};
+    HIP_TRY(ctx, launch_encrypt(p, layout, ctx->xt, km, per_block_keys && kemit, auto_waves(ctx, layout, per_block_keys != 0),
+                                ctx->nt, s));
     return AESW_OK;
 }
 
@@ -320,7 +356,7 @@ int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint6
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     KeyParams kp{d_keys, ctx->d_tables, KeyOut{d_w, d_kx, d_ky, d_kz}, d_rk, n};
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, ctx->waves_pbk, ctx->nt, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves(ctx, layout, true), ctx->nt, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 
@@ -378,7 +414,9 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
                          int layout, uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct, const aesw_key_slab *ks) {
     if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;
     if (n == 0) return AESW_OK;
-    if (!pt || !keys || !x || !y || !z) return AESW_ERR_INVALID_ARG;
+    if (!pt || !x || !y || !z) return AESW_ERR_INVALID_ARG;
+    if (!keys && (per_block_keys || (ks && (ks->w || ks->kx || ks->ky || ks->kz)))) return AESW_ERR_INVALID_ARG;
+    if (!keys && !ctx->have_key) return AESW_ERR_NO_KEY;
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     int rc = ensure_streams(ctx);
@@ -410,7 +448,7 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
     Pinned px, py, pz;
     px.pin(x, n * sx); py.pin(y, n * sy); pz.pin(z, n * sz);
     HIP_TRY(ctx, hipMemcpyAsync(d_pt.p, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
-    HIP_TRY(ctx, hipMemcpyAsync(d_keys.p, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
+    if (keys) HIP_TRY(ctx, hipMemcpyAsync(d_keys.p, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
 
     if (!pbk && kemit) {
         // shared key: one key slab, straight through
@@ -441,7 +479,7 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         const int s = it & 1;
         if (it >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_compute, copied[s], 0));  // buffer set free again
         aesw_key_slab dks{dw[s].p, dkx[s].p, dky[s].p, dkz[s].p};
-        rc = aesw_encrypt_witness_device(ctx, d_pt.p + 16 * b0, pbk ? d_keys.p + 16 * b0 : d_keys.p, per_block_keys, m,
+        rc = aesw_encrypt_witness_device(ctx, d_pt.p + 16 * b0, !keys ? nullptr : (pbk ? d_keys.p + 16 * b0 : d_keys.p), per_block_keys, m,
                                          layout, dx[s].p, dy[s].p, dz[s].p, ct ? d_ct.p + 16 * b0 : nullptr,
                                          pbk && kemit ? &dks : nullptr, ctx->s_compute);
         if (rc != AESW_OK) return rc;
@@ -492,6 +530,29 @@ int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, in
     if (ky) HIP_TRY(ctx, hipMemcpy(ky, dky.p, n * kys, hipMemcpyDeviceToHost));
     if (kz) HIP_TRY(ctx, hipMemcpy(kz, dkz.p, n * kzs, hipMemcpyDeviceToHost));
     if (rk) HIP_TRY(ctx, hipMemcpy(rk, drk.p, n * RK_BYTES, hipMemcpyDeviceToHost));
+    return AESW_OK;
+}
+
+int aesw_schedule_key(aesw_ctx *ctx, const uint8_t key[16], int layout, const aesw_key_slab *ks) {
+    if (!ctx || !valid_layout(layout) || !key) return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    const size_t kxs = aesw_key_column_stride(layout, 0), kys = aesw_key_column_stride(layout, 1),
+                 kzs = aesw_key_column_stride(layout, 2);
+    DevBuf dk, dw, dkx, dky, dkz;
+    HIP_TRY(ctx, dk.alloc(16));
+    HIP_TRY(ctx, dw.alloc(WORDS_ROWS)); HIP_TRY(ctx, dkx.alloc(kxs)); HIP_TRY(ctx, dky.alloc(kys)); HIP_TRY(ctx, dkz.alloc(kzs));
+    HIP_TRY(ctx, hipMemcpy(dk.p, key, 16, hipMemcpyHostToDevice));
+    aesw_key_slab dks{dw.p, dkx.p, dky.p, dkz.p};
+    int rc = aesw_schedule_key_device(ctx, dk.p, layout, ks ? &dks : nullptr, nullptr);
+    if (rc != AESW_OK) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if (ks) {
+        if (ks->w) HIP_TRY(ctx, hipMemcpy(ks->w, dw.p, WORDS_ROWS, hipMemcpyDeviceToHost));
+        if (ks->kx) HIP_TRY(ctx, hipMemcpy(ks->kx, dkx.p, kxs, hipMemcpyDeviceToHost));
+        if (ks->ky) HIP_TRY(ctx, hipMemcpy(ks->ky, dky.p, kys, hipMemcpyDeviceToHost));
+        if (ks->kz) HIP_TRY(ctx, hipMemcpy(ks->kz, dkz.p, kzs, hipMemcpyDeviceToHost));
+    }
     return AESW_OK;
 }
 

@@ -12,7 +12,8 @@ struct KeyOut {
 
 struct EncParams {
     const uint8_t *pt;      // n*16
-    const uint8_t *keys;    // 16 or n*16
+    const uint8_t *keys;    // 16 or n*16; null when rk is used
+    const uint32_t *rk;     // 44 words of a key scheduled earlier (aesw_schedule_key_device), or null
     const uint8_t *tables;  // 768: sbox | mul2 | mul3
     uint8_t *x, *y, *z;     // column buffers (16-byte aligned)
     uint8_t *ct;            // n*16 or null
@@ -28,7 +29,8 @@ struct KeyParams {
     uint64_t n;
 };
 
-hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, bool pbk, bool kemit, int waves, bool nt,
+// key mode: 0 = per-block keys, 1 = shared key expanded in the kernel, 2 = shared key scheduled earlier (p.rk)
+hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, bool nt,
                           hipStream_t s);
 hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool nt, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);

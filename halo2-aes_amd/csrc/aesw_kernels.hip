@@ -213,10 +213,16 @@ __device__ __forceinline__ void key_flush(const uint8_t *lds, uint32_t stage, co
 // ---------------------------------------------------------------------------
 // encrypt witness kernel
 // ---------------------------------------------------------------------------
-// PBK: per-block keys (key schedule per quad; KEMIT: also emit its witness).
-// !PBK: the shared key is expanded once per group by wave 0's first quad.
-template <int L, bool XT, bool PBK, bool KEMIT, bool NT>
+// KM_PBK: per-block keys (key schedule per quad; KEMIT: also emit its witness).
+// KM_SHARED: one key for the batch, expanded per group by wave 0's first quad.
+// KM_PRE: one key, scheduled earlier (schedule_key() once, encrypt() many
+//         times -- the reference's own call shape, benches/aes128.rs:50-53):
+//         the 44 round-key words come from global memory, no barrier for them.
+enum : int { KM_PBK = 0, KM_SHARED = 1, KM_PRE = 2 };
+
+template <int L, bool XT, int KM, bool KEMIT, bool NT>
 __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
+    constexpr bool PBK = KM == KM_PBK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using G = Geo<L>;
     using St = Stage<L>;
@@ -228,13 +234,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     const int waves = blockDim.x >> 6;
     const int blk = lane >> 2, w = lane & 3;
 
-    // tables -> LDS
-    for (int i = tid; i < TAB_BYTES / 4; i += blockDim.x)  // groups may be as small as one wave
-        reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(a.tables)[i];
-    __syncthreads();
-    const Tables<XT> tab{lds};
-
-    const uint32_t shared_rk = TAB_BYTES;                          // 176 B, !PBK only
+    const uint32_t shared_rk = TAB_BYTES;                          // 176 B, KM_SHARED only
     const uint32_t stage = TAB_BYTES + RKS_BYTES + wave * WAVE_LDS;  // this wave's slab
     const uint32_t rk_w = stage + (WAVE_LDS - St::RK_BYTES_W);      // PBK only: tail of the slab
 
@@ -243,7 +243,21 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     const int nvalid = left >= BPW ? BPW : (left > 0 ? (int)left : 0);
     const bool live = blk < nvalid;
 
-    if (!PBK) {
+    // inputs first, so their latency hides behind the table load
+    const uint32_t ptw = live ? reinterpret_cast<const uint32_t *>(a.pt)[(blk0 + blk) * 4 + w] : 0u;
+    uint32_t rkr[11];  // KM_PRE: this lane's word of every round key
+    if (KM == KM_PRE) {
+#pragma unroll
+        for (int r = 0; r < 11; ++r) rkr[r] = a.rk[4 * r + w];
+    }
+
+    // tables -> LDS
+    for (int i = tid; i < TAB_BYTES / 4; i += blockDim.x)  // groups may be as small as one wave
+        reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(a.tables)[i];
+    __syncthreads();
+    const Tables<XT> tab{lds};
+
+    if (KM == KM_SHARED) {
         if (wave == 0) {
             const uint32_t kw = reinterpret_cast<const uint32_t *>(a.keys)[w];
             NullKSink ks;
@@ -271,6 +285,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     }
     const uint32_t *rkp = PBK ? reinterpret_cast<const uint32_t *>(lds + rk_w) + blk * 44 + w
                               : reinterpret_cast<const uint32_t *>(lds + shared_rk) + w;
+    auto rkw = [&](int r) -> uint32_t { return KM == KM_PRE ? rkr[r] : rkp[4 * r]; };
 
     DevSink<L> s;
     s.lds = lds;
@@ -285,8 +300,6 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     uint8_t *gy = a.y + blk0 * G::YS;
     uint8_t *gz = a.z + blk0 * G::ZS;
 
-    const uint32_t ptw = live ? reinterpret_cast<const uint32_t *>(a.pt)[(blk0 + blk) * 4 + w] : 0u;
-
     auto round = [&](int relx, int rely, int relz, uint32_t st, uint32_t rkw) -> uint32_t {
         const uint32_t sub = emit_sbox<L>(s, relx, rely, relz, st, tab);
         const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
@@ -298,14 +311,14 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     using WX = typename St::WX;
     using WY = typename St::WY;
     using WZ = typename St::WZ;
-    uint32_t st = emit_head<L>(s, ptw, rkp[0]);
+    uint32_t st = emit_head<L>(s, ptw, rkw(0));
 #pragma unroll
     for (int R = 1; R <= 9; ++R) {
-        st = round(WX::woff(R), WY::woff(R), WZ::woff(R), st, rkp[4 * R]);
+        st = round(WX::woff(R), WY::woff(R), WZ::woff(R), st, rkw(R));
         if (R == 9) {
             const uint32_t sub = emit_sbox<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), st, tab);
             const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
-            st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkp[40]);
+            st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkw(10));
         }
         wave_lds_fence();
         flush_lines<WX, NT>(R, lds, stage + St::OX, gx, nvalid, lane);
@@ -383,14 +396,14 @@ __global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restric
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-template <int L, bool XT, bool PBK, bool KEMIT, bool NT>
+template <int L, bool XT, int KM, bool KEMIT, bool NT>
 static hipError_t launch_enc(const EncParams &p, int waves, hipStream_t stream) {
     const int bpg = waves * BPW;
     const uint64_t groups = (p.n + bpg - 1) / bpg;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(PBK, KEMIT);
-    auto k = encrypt_kernel<L, XT, PBK, KEMIT, NT>;
+    const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KM == KM_PBK, KEMIT);
+    auto k = encrypt_kernel<L, XT, KM, KEMIT, NT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -399,25 +412,26 @@ static hipError_t launch_enc(const EncParams &p, int waves, hipStream_t stream) 
     return hipGetLastError();
 }
 
-template <int L, bool XT, bool PBK, bool KEMIT>
+template <int L, bool XT, int KM, bool KEMIT>
 static hipError_t launch_enc_nt(const EncParams &p, int waves, bool nt, hipStream_t s) {
-    return nt ? launch_enc<L, XT, PBK, KEMIT, true>(p, waves, s) : launch_enc<L, XT, PBK, KEMIT, false>(p, waves, s);
+    return nt ? launch_enc<L, XT, KM, KEMIT, true>(p, waves, s) : launch_enc<L, XT, KM, KEMIT, false>(p, waves, s);
 }
 
 template <int L, bool XT>
-static hipError_t launch_enc_mode(const EncParams &p, bool pbk, bool kemit, int waves, bool nt, hipStream_t s) {
-    if (!pbk) return launch_enc_nt<L, XT, false, false>(p, waves, nt, s);
-    return kemit ? launch_enc_nt<L, XT, true, true>(p, waves, nt, s) : launch_enc_nt<L, XT, true, false>(p, waves, nt, s);
+static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, bool nt, hipStream_t s) {
+    if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, s);
+    if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, s);
+    return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, s);
 }
 
-hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, bool pbk, bool kemit, int waves, bool nt,
+hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, bool nt,
                           hipStream_t s) {
-    if (waves < 1 || waves > 4) return hipErrorInvalidValue;
+    if (waves < 1 || waves > 4 || keymode < 0 || keymode > 2) return hipErrorInvalidValue;
     if (layout == DENSE)
-        return xt ? launch_enc_mode<DENSE, true>(p, pbk, kemit, waves, nt, s)
-                  : launch_enc_mode<DENSE, false>(p, pbk, kemit, waves, nt, s);
-    return xt ? launch_enc_mode<PACKED, true>(p, pbk, kemit, waves, nt, s)
-              : launch_enc_mode<PACKED, false>(p, pbk, kemit, waves, nt, s);
+        return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, s)
+                  : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, s);
+    return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, s)
+              : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, s);
 }
 
 template <int L, bool XT, bool NT>

@@ -110,8 +110,21 @@ uint64_t aesw_block_capacity(uint32_t k, uint32_t n_sets);
 
 /* ---- device-pointer entry points (asynchronous on `stream`) -------------- */
 /* stream is a hipStream_t passed as void* (NULL = the default stream).
- * d_keys: 16 B when !per_block_keys, n*16 B otherwise.  d_ct and key_slab are
- * optional (NULL).  All pointers are device pointers on aesw_device(ctx). */
+ * All pointers are device pointers on aesw_device(ctx); column buffers must be
+ * 16-byte aligned (128-byte aligned for full speed: stores leave as whole lines).
+ *
+ * FixedAes128Config::schedule_key (src/aes128.rs:143-152): expands one key on
+ * the device, keeps its 11 round keys inside the context for later
+ * aesw_encrypt_witness_device(..., d_keys = NULL, per_block_keys = 0) calls,
+ * and optionally emits its key-schedule witness (one key slab).  This is the
+ * reference's call shape: schedule_key once, encrypt many times
+ * (benches/aes128.rs:50-53). */
+int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout,
+                             const aesw_key_slab *d_key_slab, void *stream);
+/* d_keys: n*16 B when per_block_keys; 16 B (one key, expanded inside the call)
+ * or NULL (use the key of aesw_schedule_key*; AESW_ERR_NO_KEY if there is none,
+ * where the reference panics "Keys should be scheduled") otherwise.
+ * d_ct and d_key_slab are optional (NULL). */
 int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys,
                                 int per_block_keys, uint64_t n, int layout, uint8_t *d_x,
                                 uint8_t *d_y, uint8_t *d_z, uint8_t *d_ct,
@@ -136,10 +149,13 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
                          const aesw_key_slab *key_slab);
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout,
                               uint8_t *w, uint8_t *kx, uint8_t *ky, uint8_t *kz, uint8_t *rk);
+/* host-pointer aesw_schedule_key_device: key is 16 host bytes, key_slab host buffers (optional) */
+int aesw_schedule_key(aesw_ctx *ctx, const uint8_t key[16], int layout, const aesw_key_slab *key_slab);
 int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3);
 
 /* ---- tuning / introspection (bench.py, tests) ----------------------------- */
-/* name: "variant" (kernel variant id), "nt_stores" (0/1).  Unknown -> INVALID_ARG */
+/* name: "waves_shared" / "waves_pbk" (waves per group, 0 = auto, 1..4),
+ * "nt_stores" (0/1), "force_table_path" (1), "chunk_blocks".  Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);
 /* 1 when mul2/mul3 passed to aesw_create() equal GF(2^8) xtime tables, so the

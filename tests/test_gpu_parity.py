@@ -190,6 +190,36 @@ def test_launch_options(pkg, oracle, waves, nt):
     c.close()
 
 
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+def test_schedule_key_then_encrypt(pkg, oracle, layout):
+    """The reference's call shape: schedule_key() once, encrypt() n times
+    (benches/aes128.rs:50-53); encrypt before schedule_key fails like the
+    reference's expect("Keys should be scheduled") (src/aes128.rs:170)."""
+    import torch
+    c = pkg.Context(0)
+    pt, keys = _inputs(333)
+    dpt = torch.from_numpy(pt).cuda()
+    with pytest.raises(pkg.AeswError) as e:
+        c.encrypt_witness(dpt, None, layout=layout)
+    assert e.value.status == 6
+    kw = c.schedule_key(torch.from_numpy(keys[7]).cuda(), layout=layout)
+    got = c.encrypt_witness(dpt, None, layout=layout, want_ct=True)
+    torch.cuda.synchronize()
+    exp = oracle.encrypt_witness(pt, keys[7], layout=layout)
+    for col in "xyz":
+        _cmp(col, getattr(got, col), getattr(exp, col))
+    _cmp("ct", got.ct, exp.ct)
+    kexp = oracle.key_schedule_witness(keys[7], layout=layout)
+    for col in ("w", "kx", "ky", "kz"):
+        _cmp(col, getattr(kw, col), getattr(kexp, col))
+    # a new key replaces the old one
+    c.schedule_key(torch.from_numpy(keys[8]).cuda(), layout=layout, key_slab=False)
+    got = c.encrypt_witness(dpt, None, layout=layout)
+    torch.cuda.synchronize()
+    _cmp("x", got.x, oracle.encrypt_witness(pt, keys[8], layout=layout).x)
+    c.close()
+
+
 def test_config1_single_block(ctx):
     """BASELINE config 0: one block, fixed zero key (benches/aes128.rs shape)."""
     import torch
