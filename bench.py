@@ -249,12 +249,58 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # keep the headline even if an extra fails
                 extras[name] = {"error": str(e)}
+        try:  # PCIe-inclusive rate of the host-pointer entry point (never `value`)
+            import numpy as np
+            nn = 1 << 16
+            hpt = np.random.default_rng(SEED).integers(0, 256, (nn, 16), dtype=np.uint8)
+            ctx.encrypt_witness_host(hpt[:1024], None, layout=pkg.LAYOUT_PACKED)  # warm-up (streams, first touch)
+            t0 = time.perf_counter()
+            ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_PACKED)
+            dt = time.perf_counter() - t0
+            extras["pcie_inclusive"] = {"blocks": nn, "blocks_per_s": nn / dt, "GBps_to_host": nn * 3024 / dt / 1e9,
+                                        "note": "aesw_encrypt_witness: H2D + kernel + D2H into pageable caller memory"}
+        except Exception as e:
+            extras["pcie_inclusive"] = {"error": str(e)}
+        try:  # byte cells -> 32-byte Fr cells
+            cells = torch.randint(0, 256, (1 << 26,), dtype=torch.uint8, device="cuda")
+            out = torch.empty((1 << 26, 32), dtype=torch.uint8, device="cuda")
+            ctx.expand_fr(cells, out)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ctx.expand_fr(cells, out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            extras["expand_fr"] = {"cells": 1 << 26, "launch_ms": ms, "written_GBps": (1 << 26) * 32 / (ms * 1e-3) / 1e9}
+            del cells, out
+        except Exception as e:
+            extras["expand_fr"] = {"error": str(e)}
         line["extra"] = extras
     if rank == 0 and world == 1 and not a.no_cpu:
         line["cpu_baseline"] = cpu_baseline()
     elif rank == 0:
         line["cpu_baseline"] = None
     if dist is not None:
+        # optional exchange step, timed separately (never part of `value`): gather every rank's columns on rank 0
+        try:
+            strides = [pkg.column_stride(layout, c) for c in range(3)]
+            wset = runner.sets[0]
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            full = pkg.sharding.gather_columns([wset.x, wset.y, wset.z], [n] * world, strides, dst=0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = time.perf_counter() - t0
+            if rank == 0:
+                line["gather"] = {"seconds": dt, "GBps_into_root": (world - 1) * n * sum(strides) / dt / 1e9,
+                                  "note": "RCCL send/recv of per-rank column ranges to rank 0, outside `value`"}
+            del full
+        except Exception as e:
+            if rank == 0:
+                line["gather"] = {"error": str(e)}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -352,11 +352,16 @@ class Context:
     def encrypt_witness_host(self, pt: np.ndarray, keys: np.ndarray, layout: int = K.LAYOUT_PACKED,
                              want_ct: bool = False, key_slab: bool = False):
         pt = np.ascontiguousarray(pt, dtype=np.uint8).reshape(-1, 16)
-        keys = np.ascontiguousarray(keys, dtype=np.uint8)
         n = pt.shape[0]
-        pbk = 0 if keys.size == 16 else 1
-        if pbk and keys.size != n * 16:
-            raise ValueError("keys must hold 16 or n*16 bytes")
+        if keys is None:  # the key given to schedule_key()
+            pbk = 0
+            if key_slab:
+                raise ValueError("the key slab of a scheduled key is returned by schedule_key()")
+        else:
+            keys = np.ascontiguousarray(keys, dtype=np.uint8)
+            pbk = 0 if keys.size == 16 else 1
+            if pbk and keys.size != n * 16:
+                raise ValueError("keys must hold 16 or n*16 bytes")
         cols = [np.empty(n * column_stride(layout, c), dtype=np.uint8) for c in range(3)]
         ct = np.empty((n, 16), dtype=np.uint8) if want_ct else None
         key = ks = None
@@ -365,7 +370,8 @@ class Context:
             key = KeyWitness(np.empty(m * K.WORDS_ROWS, np.uint8),
                              *[np.empty(m * key_column_stride(layout, c), np.uint8) for c in range(3)], None)
             ks = KeySlab(*[a.ctypes.data for a in key[:4]])
-        rc = self._lib.aesw_encrypt_witness(self._h, _np_ptr(pt), _np_ptr(keys), pbk, n, layout, *[_np_ptr(c) for c in cols],
+        rc = self._lib.aesw_encrypt_witness(self._h, _np_ptr(pt), _np_ptr(keys) if keys is not None else None, pbk, n, layout,
+                                            *[_np_ptr(c) for c in cols],
                                             _np_ptr(ct) if ct is not None else None, C.byref(ks) if ks is not None else None)
         self._check(rc, "aesw_encrypt_witness")
         return Witness(cols[0], cols[1], cols[2], ct, key)

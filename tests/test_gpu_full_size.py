@@ -1,0 +1,150 @@
+"""BASELINE.json's full sizes on the GPU.
+
+config 2 (2^20 blocks, per-block keys, fused key-schedule witness): compared
+byte-for-byte with the oracle (the GPU box has enough host cores for that) AND
+re-verified by size-independent properties computed with plain torch ops,
+independent of the kernels: every relation the reference's lookups and copy
+constraints impose on a slab (what MockProver checks), for all 2^20 blocks.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+MIX = [[2, 3, 1, 1], [1, 2, 3, 1], [1, 1, 2, 3], [3, 1, 1, 2]]
+
+
+def _check_slab_relations(torch, pkg, x, y, z, pt, rk, sbox, mul2, mul3):
+    """x,y,z: [n,1360] dense uint8 on the GPU; rk: [n,176]; raises on the first violated relation."""
+    S, M2, M3 = [torch.from_numpy(t.astype(np.int64)).cuda() for t in (sbox, mul2, mul3)]
+
+    def tab(T, v):
+        return T[v.long()].to(torch.uint8)
+
+    def eq(a, b, what):
+        if not torch.equal(a, b):
+            bad = (a != b).nonzero()[0].tolist()
+            raise AssertionError("%s violated at block %d, offset %d" % (what, bad[0], bad[1]))
+
+    eq(x[:, 0:16], pt, "rows 0-15 x == plaintext")
+    eq(x[:, 16:32], pt, "rows 16-31 x == plaintext (copy)")
+    eq(y[:, 16:32], rk[:, 0:16], "rows 16-31 y == rk0 (copy)")
+    eq(z[:, 16:32], x[:, 16:32] ^ y[:, 16:32], "initial AddRoundKey xor lookup")
+    state = z[:, 16:32]
+    for R in range(1, 11):
+        B = 32 + 144 * (R - 1)
+        eq(x[:, B:B + 16], state, "round %d sbox x == previous state (copy)" % R)
+        sub = y[:, B:B + 16]
+        eq(sub, tab(S, x[:, B:B + 16]), "round %d sbox lookup" % R)
+        sh = torch.stack([sub[:, 4 * ((w + j) % 4) + j] for w in range(4) for j in range(4)], dim=1)  # ShiftRows
+        if R < 10:
+            mixed = []
+            for w in range(4):
+                for m in range(4):
+                    r0 = B + 16 + 7 * (4 * w + m)
+                    tmp = []
+                    for t in range(4):
+                        a = sh[:, 4 * w + t]
+                        eq(x[:, r0 + t], a, "round %d lcon x == shifted byte (copy)" % R)
+                        c = MIX[m][t]
+                        if c == 1:
+                            tmp.append(a)
+                        else:
+                            eq(y[:, r0 + t], tab(M2 if c == 2 else M3, a), "round %d mul%d lookup" % (R, c))
+                            tmp.append(y[:, r0 + t])
+                    eq(x[:, r0 + 4], tmp[0], "lcon row 4 x (copy)"); eq(y[:, r0 + 4], tmp[1], "lcon row 4 y (copy)")
+                    eq(z[:, r0 + 4], tmp[0] ^ tmp[1], "lcon row 4 xor lookup")
+                    eq(x[:, r0 + 5], tmp[2], "lcon row 5 x (copy)"); eq(y[:, r0 + 5], tmp[3], "lcon row 5 y (copy)")
+                    eq(z[:, r0 + 5], tmp[2] ^ tmp[3], "lcon row 5 xor lookup")
+                    eq(x[:, r0 + 6], z[:, r0 + 4], "lcon row 6 x (copy)"); eq(y[:, r0 + 6], z[:, r0 + 5], "lcon row 6 y (copy)")
+                    eq(z[:, r0 + 6], x[:, r0 + 6] ^ y[:, r0 + 6], "lcon row 6 xor lookup")
+                    mixed.append(z[:, r0 + 6])
+            mixed = torch.stack(mixed, dim=1)
+            A = B + 128
+        else:
+            mixed = sh
+            A = 1344
+        eq(x[:, A:A + 16], mixed, "round %d AddRoundKey x == mixed (copy)" % R)
+        eq(y[:, A:A + 16], rk[:, 16 * R:16 * R + 16], "round %d AddRoundKey y == round key (copy)" % R)
+        eq(z[:, A:A + 16], x[:, A:A + 16] ^ y[:, A:A + 16], "round %d AddRoundKey xor lookup" % R)
+        state = z[:, A:A + 16]
+    return state  # ciphertext
+
+
+def _unpack(torch, col, idx, n, stride):
+    """packed [n*stride] -> dense [n,1360] with zeros in never-assigned cells."""
+    dense = torch.zeros((n, 1360), dtype=torch.uint8, device=col.device)
+    live = torch.from_numpy(np.nonzero(idx >= 0)[0]).cuda()
+    dense[:, live] = col.view(n, stride)
+    return dense
+
+
+def test_config3_2p20_per_block_keys(ctx, pkg, oracle):
+    import torch
+    n = 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(0xA35128 + 2)
+    pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g)
+    keys = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g)
+    dpt, dkeys = pt.cuda(), keys.cuda()
+    got = ctx.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
+    kw = ctx.key_schedule_witness(dkeys, layout=pkg.LAYOUT_PACKED)   # separate kernel: must agree with the fused one
+    torch.cuda.synchronize()
+    for c in ("w", "kx", "ky", "kz"):
+        assert torch.equal(getattr(got.key, c), getattr(kw, c)), "fused and standalone key witness differ in " + c
+
+    # (1) properties, all 2^20 blocks, torch ops only
+    sbox, mul2, mul3 = pkg.reference_tables()
+    x = got.x.view(n, 1360)
+    y = _unpack(torch, got.y, pkg.packed_index(1), n, 1056)
+    z = _unpack(torch, got.z, pkg.packed_index(2), n, 608)
+    ct = _check_slab_relations(torch, pkg, x, y, z, dpt, kw.rk, sbox, mul2, mul3)
+    assert torch.equal(ct, got.ct)
+    # round keys: words_column and the range-check rows hold them (copy constraints of the key schedule)
+    assert torch.equal(kw.w.view(n, 96)[:, :16], dkeys)
+    kx = kw.kx.view(n, 400)
+    for rho in range(1, 11):
+        assert torch.equal(kx[:, 40 * (rho - 1) + 24:40 * rho], kw.rk[:, 16 * rho:16 * rho + 16])
+    del x, y, z
+
+    # (2) every byte against the oracle
+    threads = min(64, os.cpu_count() or 8)
+    exp = oracle.encrypt_witness(pt.numpy(), keys.numpy(), layout=ol.PACKED, threads=threads)
+    for c in "xyz":
+        assert np.array_equal(getattr(got, c).cpu().numpy(), getattr(exp, c)), "column %s differs from the oracle" % c
+    assert np.array_equal(got.ct.cpu().numpy(), exp.ct)
+    del exp
+    kexp = oracle.key_schedule_witness(keys.numpy(), layout=ol.PACKED, threads=threads)
+    for c in ("w", "kx", "ky", "kz", "rk"):
+        assert np.array_equal(getattr(kw, c).cpu().numpy().reshape(-1), getattr(kexp, c).reshape(-1)), c
+
+
+def test_dense_2p20_shared_key_properties(ctx, pkg, oracle):
+    """Dense layout at 2^20 blocks: relations + never-assigned cells are zero + a sampled oracle comparison."""
+    import torch
+    n = 1 << 20
+    g = torch.Generator(device="cpu").manual_seed(0xA35128 + 3)
+    pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g)
+    key = torch.randint(0, 256, (16,), dtype=torch.uint8, generator=g)
+    dpt, dkey = pt.cuda(), key.cuda()
+    kw = ctx.schedule_key(dkey, layout=pkg.LAYOUT_DENSE)
+    got = ctx.encrypt_witness(dpt, None, layout=pkg.LAYOUT_DENSE, want_ct=True)
+    rk = ctx.key_schedule_witness(dkey, layout=pkg.LAYOUT_DENSE).rk
+    torch.cuda.synchronize()
+    x, y, z = got.x.view(n, 1360), got.y.view(n, 1360), got.z.view(n, 1360)
+    ct = _check_slab_relations(torch, pkg, x, y, z, dpt, rk.expand(n, 176), *pkg.reference_tables())
+    assert torch.equal(ct, got.ct)
+    for c, col in ((1, y), (2, z)):
+        dead = torch.from_numpy(np.nonzero(pkg.packed_index(c) < 0)[0]).cuda()
+        assert int(col[:, dead].max()) == 0, "never-assigned cells must be zero in the dense layout"
+    sample = np.random.default_rng(1).choice(n, 4096, replace=False)
+    exp = oracle.encrypt_witness(pt.numpy()[sample], key.numpy(), layout=ol.DENSE)
+    ds = torch.from_numpy(sample).cuda()
+    for name, col in (("x", x), ("y", y), ("z", z)):
+        assert np.array_equal(col[ds].cpu().numpy().reshape(-1), getattr(exp, name))
+    kexp = oracle.key_schedule_witness(key.numpy(), layout=ol.DENSE)
+    for c in ("w", "kx", "ky", "kz"):
+        assert np.array_equal(getattr(kw, c).cpu().numpy(), getattr(kexp, c))
