@@ -64,6 +64,8 @@ SYMBOLS = {
     "aesw_encrypt_witness": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab)]),
     "aesw_key_schedule_witness": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P]),
     "aesw_lookup_table": (_I, [_P, _P, _P, _P, _P]),
+    "aesw_host_alloc": (_P, [C.c_size_t]),
+    "aesw_host_free": (None, [_P]),
     "aesw_set_option": (_I, [_P, C.c_char_p, _I64]),
     "aesw_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I64)]),
     "aesw_uses_xtime_path": (_I, [_P]),
@@ -155,6 +157,26 @@ def device_count() -> int:
     load_library().aesw_device_count(C.byref(n))
     return int(n.value)
 
+
+def host_alloc(nbytes: int) -> np.ndarray:
+    """Page-locked uint8 host buffer (aesw_host_alloc): D2H lands in it without a bounce copy."""
+    lib = load_library()
+    p = lib.aesw_host_alloc(nbytes)
+    if not p:
+        raise MemoryError("aesw_host_alloc(%d) failed" % nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    _pinned[arr.ctypes.data] = p
+    return arr
+
+
+def host_free(arr: np.ndarray):
+    p = _pinned.pop(arr.ctypes.data, None)
+    if p:
+        load_library().aesw_host_free(p)
+
+
+_pinned = {}
 
 Witness = namedtuple("Witness", "x y z ct key")
 KeyWitness = namedtuple("KeyWitness", "w kx ky kz rk")
@@ -350,7 +372,7 @@ class Context:
 
     # -- host entry points (numpy in, numpy out)
     def encrypt_witness_host(self, pt: np.ndarray, keys: np.ndarray, layout: int = K.LAYOUT_PACKED,
-                             want_ct: bool = False, key_slab: bool = False):
+                             want_ct: bool = False, key_slab: bool = False, out_cols=None):
         pt = np.ascontiguousarray(pt, dtype=np.uint8).reshape(-1, 16)
         n = pt.shape[0]
         if keys is None:  # the key given to schedule_key()
@@ -362,7 +384,8 @@ class Context:
             pbk = 0 if keys.size == 16 else 1
             if pbk and keys.size != n * 16:
                 raise ValueError("keys must hold 16 or n*16 bytes")
-        cols = [np.empty(n * column_stride(layout, c), dtype=np.uint8) for c in range(3)]
+        cols = list(out_cols) if out_cols is not None else [np.empty(n * column_stride(layout, c), dtype=np.uint8)
+                                                            for c in range(3)]
         ct = np.empty((n, 16), dtype=np.uint8) if want_ct else None
         key = ks = None
         if key_slab:

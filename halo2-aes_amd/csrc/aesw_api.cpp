@@ -27,6 +27,10 @@ struct aesw_ctx {
     int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
     std::string last_error;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
+    uint8_t *bounce[2] = {nullptr, nullptr};  // page-locked staging for pageable destinations
+    size_t bounce_bytes = 0;
+    uint8_t *scratch = nullptr;  // device buffers of the host-pointer path (grow-only)
+    size_t scratch_bytes = 0;
 };
 
 namespace {
@@ -183,6 +187,9 @@ void aesw_destroy(aesw_ctx *ctx) {
         DeviceGuard g(ctx->device);
         if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
         if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+        for (int i = 0; i < 2; ++i)
+            if (ctx->bounce[i]) (void)hipHostFree(ctx->bounce[i]);
+        if (ctx->scratch) (void)hipFree(ctx->scratch);
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
         if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
         if (ctx->d_rk) (void)hipFree(ctx->d_rk);
@@ -396,16 +403,44 @@ int ensure_streams(aesw_ctx *ctx) {
     return AESW_OK;
 }
 
-// Pin the caller's output range for the duration of a call so D2H is truly async.
-struct Pinned {
-    void *p = nullptr;
-    bool ok = false;
-    void pin(void *ptr, size_t n) {
-        if (!ptr || !n) return;
-        ok = hipHostRegister(ptr, n, hipHostRegisterDefault) == hipSuccess;
-        if (ok) p = ptr; else (void)hipGetLastError();
+bool is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
     }
-    ~Pinned() { if (ok) (void)hipHostUnregister(p); }
+    return at.type == hipMemoryTypeHost;
+}
+
+int ensure_bounce(aesw_ctx *ctx, size_t bytes) {
+    if (ctx->bounce_bytes >= bytes) return AESW_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->bounce[i]) (void)hipHostFree(ctx->bounce[i]);
+        ctx->bounce[i] = nullptr;
+    }
+    ctx->bounce_bytes = 0;
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->bounce[i]), bytes, hipHostMallocDefault));
+    ctx->bounce_bytes = bytes;
+    return AESW_OK;
+}
+
+int ensure_scratch(aesw_ctx *ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return AESW_OK;
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->scratch), bytes));
+    ctx->scratch_bytes = bytes;
+    return AESW_OK;
+}
+
+// One output column of the host path: where chunk data goes and how.
+struct HostCol {
+    uint8_t *dst;       // caller buffer (null = not wanted)
+    const uint8_t *dev[2];
+    size_t stride;      // bytes per block
+    bool direct;        // caller buffer is page-locked: DMA straight into it
+    size_t boff;        // offset inside the bounce buffer
 };
 
 }  // namespace
@@ -430,23 +465,48 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
     if (chunk > n) chunk = n;
     chunk = (chunk + 63) / 64 * 64;
 
-    DevBuf d_pt, d_keys, d_ct, dx[2], dy[2], dz[2], dw[2], dkx[2], dky[2], dkz[2];
-    HIP_TRY(ctx, d_pt.alloc(n * 16));
-    HIP_TRY(ctx, d_keys.alloc(pbk ? n * 16 : 16));
-    if (ct) HIP_TRY(ctx, d_ct.alloc(n * 16));
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(ctx, dx[i].alloc(chunk * sx));
-        HIP_TRY(ctx, dy[i].alloc(chunk * sy));
-        HIP_TRY(ctx, dz[i].alloc(chunk * sz));
-        if (pbk && kemit) {
-            HIP_TRY(ctx, dw[i].alloc(chunk * WORDS_ROWS));
-            HIP_TRY(ctx, dkx[i].alloc(chunk * kxs));
-            HIP_TRY(ctx, dky[i].alloc(chunk * kys));
-            HIP_TRY(ctx, dkz[i].alloc(chunk * kzs));
+    // carve the context's device scratch: inputs, ciphertext, two sets of output columns
+    struct Carve { uint8_t *p = nullptr; };
+    Carve d_pt, d_keys, d_ct, dx[2], dy[2], dz[2], dw[2], dkx[2], dky[2], dkz[2];
+    {
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+        const size_t o_pt = take(n * 16), o_keys = take(pbk ? n * 16 : 16), o_ct = take(ct ? n * 16 : 0);
+        size_t o_x[2], o_y[2], o_z[2], o_w[2], o_kx[2], o_ky[2], o_kz[2];
+        for (int i = 0; i < 2; ++i) {
+            o_x[i] = take(chunk * sx); o_y[i] = take(chunk * sy); o_z[i] = take(chunk * sz);
+            const bool k = pbk && kemit;
+            o_w[i] = take(k ? chunk * WORDS_ROWS : 0); o_kx[i] = take(k ? chunk * kxs : 0);
+            o_ky[i] = take(k ? chunk * kys : 0); o_kz[i] = take(k ? chunk * kzs : 0);
+        }
+        rc = ensure_scratch(ctx, off ? off : 256);
+        if (rc != AESW_OK) return rc;
+        uint8_t *b = ctx->scratch;
+        d_pt.p = b + o_pt; d_keys.p = b + o_keys; d_ct.p = b + o_ct;
+        for (int i = 0; i < 2; ++i) {
+            dx[i].p = b + o_x[i]; dy[i].p = b + o_y[i]; dz[i].p = b + o_z[i];
+            dw[i].p = b + o_w[i]; dkx[i].p = b + o_kx[i]; dky[i].p = b + o_ky[i]; dkz[i].p = b + o_kz[i];
         }
     }
-    Pinned px, py, pz;
-    px.pin(x, n * sx); py.pin(y, n * sy); pz.pin(z, n * sz);
+    HostCol cols[7] = {
+        {x, {dx[0].p, dx[1].p}, sx, false, 0}, {y, {dy[0].p, dy[1].p}, sy, false, 0}, {z, {dz[0].p, dz[1].p}, sz, false, 0},
+        {pbk && kemit ? ks->w : nullptr, {dw[0].p, dw[1].p}, WORDS_ROWS, false, 0},
+        {pbk && kemit ? ks->kx : nullptr, {dkx[0].p, dkx[1].p}, kxs, false, 0},
+        {pbk && kemit ? ks->ky : nullptr, {dky[0].p, dky[1].p}, kys, false, 0},
+        {pbk && kemit ? ks->kz : nullptr, {dkz[0].p, dkz[1].p}, kzs, false, 0}};
+    size_t bounce_need = 0;
+    for (HostCol &c : cols) {
+        if (!c.dst) continue;
+        c.direct = is_pinned(c.dst);
+        if (!c.direct) {
+            c.boff = bounce_need;
+            bounce_need += (chunk * c.stride + 255) / 256 * 256;
+        }
+    }
+    if (bounce_need) {
+        rc = ensure_bounce(ctx, bounce_need);
+        if (rc != AESW_OK) return rc;
+    }
     HIP_TRY(ctx, hipMemcpyAsync(d_pt.p, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
     if (keys) HIP_TRY(ctx, hipMemcpyAsync(d_keys.p, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
 
@@ -472,12 +532,25 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         HIP_TRY(ctx, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
     }
+    // Drain stage s: wait for its D2H, then move bounce data into pageable destinations.
+    uint64_t stage_b0[2] = {0, 0}, stage_m[2] = {0, 0};
+    bool stage_busy[2] = {false, false};
+    auto drain = [&](int s) -> int {
+        if (!stage_busy[s]) return AESW_OK;
+        HIP_TRY(ctx, hipEventSynchronize(copied[s]));
+        for (const HostCol &c : cols)
+            if (c.dst && !c.direct)
+                std::memcpy(c.dst + stage_b0[s] * c.stride, ctx->bounce[s] + c.boff, stage_m[s] * c.stride);
+        stage_busy[s] = false;
+        return AESW_OK;
+    };
     uint64_t b0 = 0;
     int it = 0;
     while (b0 < n) {
         const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
         const int s = it & 1;
-        if (it >= 2) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_compute, copied[s], 0));  // buffer set free again
+        rc = drain(s);  // device buffers and bounce buffer of this stage are free again
+        if (rc != AESW_OK) return rc;
         aesw_key_slab dks{dw[s].p, dkx[s].p, dky[s].p, dkz[s].p};
         rc = aesw_encrypt_witness_device(ctx, d_pt.p + 16 * b0, !keys ? nullptr : (pbk ? d_keys.p + 16 * b0 : d_keys.p), per_block_keys, m,
                                          layout, dx[s].p, dy[s].p, dz[s].p, ct ? d_ct.p + 16 * b0 : nullptr,
@@ -485,19 +558,22 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         if (rc != AESW_OK) return rc;
         HIP_TRY(ctx, hipEventRecord(done[s], ctx->s_compute));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
-        HIP_TRY(ctx, hipMemcpyAsync(x + b0 * sx, dx[s].p, m * sx, hipMemcpyDeviceToHost, ctx->s_copy));
-        HIP_TRY(ctx, hipMemcpyAsync(y + b0 * sy, dy[s].p, m * sy, hipMemcpyDeviceToHost, ctx->s_copy));
-        HIP_TRY(ctx, hipMemcpyAsync(z + b0 * sz, dz[s].p, m * sz, hipMemcpyDeviceToHost, ctx->s_copy));
-        if (pbk && kemit) {
-            if (ks->w) HIP_TRY(ctx, hipMemcpyAsync(ks->w + b0 * WORDS_ROWS, dw[s].p, m * WORDS_ROWS, hipMemcpyDeviceToHost, ctx->s_copy));
-            if (ks->kx) HIP_TRY(ctx, hipMemcpyAsync(ks->kx + b0 * kxs, dkx[s].p, m * kxs, hipMemcpyDeviceToHost, ctx->s_copy));
-            if (ks->ky) HIP_TRY(ctx, hipMemcpyAsync(ks->ky + b0 * kys, dky[s].p, m * kys, hipMemcpyDeviceToHost, ctx->s_copy));
-            if (ks->kz) HIP_TRY(ctx, hipMemcpyAsync(ks->kz + b0 * kzs, dkz[s].p, m * kzs, hipMemcpyDeviceToHost, ctx->s_copy));
+        for (const HostCol &c : cols) {
+            if (!c.dst) continue;
+            uint8_t *to = c.direct ? c.dst + b0 * c.stride : ctx->bounce[s] + c.boff;
+            HIP_TRY(ctx, hipMemcpyAsync(to, c.dev[s], m * c.stride, hipMemcpyDeviceToHost, ctx->s_copy));
         }
         HIP_TRY(ctx, hipEventRecord(copied[s], ctx->s_copy));
+        stage_b0[s] = b0;
+        stage_m[s] = m;
+        stage_busy[s] = true;
         b0 += m;
         ++it;
     }
+    rc = drain(it & 1);
+    if (rc != AESW_OK) return rc;
+    rc = drain((it + 1) & 1);
+    if (rc != AESW_OK) return rc;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->s_copy));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->s_compute));
     if (ct) HIP_TRY(ctx, hipMemcpy(ct, d_ct.p, n * 16, hipMemcpyDeviceToHost));
@@ -554,6 +630,19 @@ int aesw_schedule_key(aesw_ctx *ctx, const uint8_t key[16], int layout, const ae
         if (ks->kz) HIP_TRY(ctx, hipMemcpy(ks->kz, dkz.p, kzs, hipMemcpyDeviceToHost));
     }
     return AESW_OK;
+}
+
+void *aesw_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void aesw_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3) {

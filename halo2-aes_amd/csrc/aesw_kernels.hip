@@ -379,17 +379,31 @@ __global__ void __launch_bounds__(256) table_kernel(const uint8_t *__restrict__ 
 // byte cells -> bn256::Fr Montgomery cells
 // ---------------------------------------------------------------------------
 // fr_lut: 256 x 32 B (value v -> v*R mod p, little-endian), built on the host.
-// One lane writes one 16-byte half cell, so a wave stores 1 KiB contiguously.
+// One lane writes one 16-byte half cell, so a wave stores 1 KiB contiguously;
+// each wave owns UNROLL KiB-pieces per trip and issues all its byte loads, then
+// all LUT reads, then all stores, to keep >= 8 KiB in flight per wave.
 __global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restrict__ cells, uint64_t n_cells,
                                                        const u32x4 *__restrict__ fr_lut, u32x4 *__restrict__ out) {
     __shared__ u32x4 lut[512];
     for (int i = threadIdx.x; i < 512; i += blockDim.x) lut[i] = fr_lut[i];
     __syncthreads();
-    const uint64_t total = n_cells * 2;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const uint32_t v = cells[i >> 1];
-        out[i] = lut[v * 2 + (uint32_t)(i & 1)];
+    constexpr int UNROLL = 8;
+    const uint64_t total = n_cells * 2;  // 16-byte pieces
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave * (UNROLL * 64); base < total; base += nwaves * (UNROLL * 64)) {
+        uint32_t v[UNROLL];
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const uint64_t i = base + j * 64 + lane;
+            v[j] = i < total ? cells[i >> 1] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < UNROLL; ++j) {
+            const uint64_t i = base + j * 64 + lane;
+            if (i < total) __builtin_nontemporal_store(lut[v[j] * 2 + (uint32_t)(i & 1)], &out[i]);
+        }
     }
 }
 
@@ -467,8 +481,8 @@ hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t
 
 hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, hipStream_t s) {
     if (n_cells == 0) return hipSuccess;
-    uint64_t blocks = (n_cells * 2 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    uint64_t blocks = (n_cells * 2 + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(expand_fr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells,
                        reinterpret_cast<const u32x4 *>(fr_lut), reinterpret_cast<u32x4 *>(out));
     return hipGetLastError();

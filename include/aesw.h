@@ -142,8 +142,13 @@ int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cell
                           void *stream);
 
 /* ---- host-pointer entry points (synchronous) ----------------------------- */
-/* Same contracts with host buffers; copies are chunked and overlapped with the
- * kernels on two streams (config 5 of BASELINE.json). */
+/* Same contracts with host buffers.  Blocks are cut into chunks ("chunk_blocks"
+ * option); chunk i's kernel runs while chunk i-1's columns travel D2H on a
+ * second stream (config 5 of BASELINE.json).  Output buffers obtained from
+ * aesw_host_alloc() are page-locked and receive the DMA directly; ordinary
+ * (pageable) buffers go through page-locked bounce buffers owned by the context. */
+void *aesw_host_alloc(size_t bytes);
+void aesw_host_free(void *p);
 int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys,
                          uint64_t n, int layout, uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct,
                          const aesw_key_slab *key_slab);

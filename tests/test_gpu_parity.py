@@ -293,6 +293,25 @@ def test_host_pointer_path(ctx, oracle):
         ctx.set_option("chunk_blocks", 1 << 15)
 
 
+def test_host_pointer_path_pinned_outputs(ctx, pkg, oracle):
+    """Page-locked caller buffers (aesw_host_alloc) take the direct-DMA branch."""
+    pt, keys = _inputs(3000)
+    ctx.set_option("chunk_blocks", 1024)
+    outs = [pkg.api.host_alloc(3000 * pkg.column_stride(ol.PACKED, c)) for c in range(3)]
+    try:
+        import torch
+        ctx.schedule_key(torch.from_numpy(keys[0]).cuda(), layout=ol.PACKED, key_slab=False)
+        torch.cuda.synchronize()
+        got = ctx.encrypt_witness_host(pt, None, layout=ol.PACKED, out_cols=outs)
+        exp = oracle.encrypt_witness(pt, keys[0], layout=ol.PACKED)
+        for c in "xyz":
+            _cmp(c, getattr(got, c), getattr(exp, c))
+    finally:
+        for o in outs:
+            pkg.api.host_free(o)
+        ctx.set_option("chunk_blocks", 1 << 15)
+
+
 def test_argument_errors(ctx, pkg):
     import torch
     pt = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
