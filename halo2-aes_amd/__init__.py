@@ -7,6 +7,8 @@ register it as the module ``halo2_aes_amd``.
 
 Layout:
   csrc/        HIP kernels (gfx950) + the C ABI of include/aesw.h
+  host/        C++ mirror of the reference's interface (FixedAes128Config, chips,
+               Aes128KeyScheduleConfig, load_enc_full_table, MockProver) above the C ABI
   api.py       ctypes binding of the C ABI, tensor plumbing (torch)
   sharding.py  one-process-per-GPU block sharding and the optional RCCL gather
   constants.py the host's byte tables (src/constant.rs) and row constants
@@ -15,13 +17,13 @@ Layout:
 from . import constants
 from .constants import (AES_ROWS, KEY_ROWS, KEY_SCHEDULE_ROWS, LAYOUT_DENSE, LAYOUT_PACKED, TABLE_ROWS, WORDS_ROWS,
                         fips_tables, reference_tables)
-from .api import (AeswError, Context, KeyWitness, Witness, block_capacity, block_placement, column_stride,
-                  device_count, key_column_stride, key_packed_index, load_library, packed_index)
+from .api import (AeswError, Context, HostCircuit, KeyWitness, Witness, block_capacity, block_placement, column_stride,
+                  device_count, key_column_stride, key_packed_index, load_library, packed_index, selector_tags)
 from . import sharding
 
 __all__ = [
     "constants", "AES_ROWS", "KEY_ROWS", "KEY_SCHEDULE_ROWS", "LAYOUT_DENSE", "LAYOUT_PACKED", "TABLE_ROWS",
-    "WORDS_ROWS", "fips_tables", "reference_tables", "AeswError", "Context", "KeyWitness", "Witness",
+    "WORDS_ROWS", "fips_tables", "reference_tables", "AeswError", "Context", "HostCircuit", "KeyWitness", "Witness",
     "block_capacity", "block_placement", "column_stride", "device_count", "key_column_stride", "key_packed_index",
-    "load_library", "packed_index", "sharding",
+    "load_library", "packed_index", "selector_tags", "sharding",
 ]

@@ -41,8 +41,10 @@ def hipcc_path() -> str:
 
 
 def build_product(force: bool = False) -> Path:
-    srcs = [CSRC / "aesw_kernels.hip", CSRC / "aesw_api.cpp"]
-    deps = srcs + [CSRC / "aesw_lane.h", CSRC / "aesw_layout.h", CSRC / "aesw_internal.h", ROOT / "include" / "aesw.h"]
+    host = PKG / "host"
+    srcs = [CSRC / "aesw_kernels.hip", CSRC / "aesw_api.cpp", host / "host_capi.cpp"]
+    deps = srcs + [CSRC / "aesw_lane.h", CSRC / "aesw_layout.h", CSRC / "aesw_internal.h", ROOT / "include" / "aesw.h",
+                   ROOT / "include" / "aesw_host.h", host / "halo2_lite.hpp", host / "aes_gadget.hpp"]
     if not force and _newer(LIB, deps):
         return LIB
     tmp = LIB.with_suffix(".so.tmp")

@@ -55,6 +55,7 @@ SYMBOLS = {
     "aesw_key_packed_index": (_I, [_I, _P]),
     "aesw_block_placement": (_I, [_U32, _U32, _U64, C.POINTER(_U32), C.POINTER(_U64)]),
     "aesw_block_capacity": (_U64, [_U32, _U32]),
+    "aesw_selector_tags": (_I, [_P, _P, _P, _P]),
     "aesw_schedule_key_device": (_I, [_P, _P, _I, C.POINTER(KeySlab), _P]),
     "aesw_schedule_key": (_I, [_P, _P, _I, C.POINTER(KeySlab)]),
     "aesw_encrypt_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P]),
@@ -69,6 +70,28 @@ SYMBOLS = {
     "aesw_set_option": (_I, [_P, C.c_char_p, _I64]),
     "aesw_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I64)]),
     "aesw_uses_xtime_path": (_I, [_P]),
+}
+
+# include/aesw_host.h: the host-side mirror of the reference's circuits
+HOST_SYMBOLS = {
+    "aesw_host_aes_circuit_run": (_I, [_P, _U32, _U32, _P, _P, _U64, _I, _I, C.POINTER(_P)]),
+    "aesw_host_key_circuit_run": (_I, [_P, _U32, _P, C.POINTER(_P)]),
+    "aesw_host_circuit_free": (None, [_P]),
+    "aesw_host_circuit_verify": (_I, [_P, C.c_char_p, C.c_size_t]),
+    "aesw_host_circuit_num_advice": (_U32, [_P]),
+    "aesw_host_circuit_num_selectors": (_U32, [_P]),
+    "aesw_host_circuit_num_rows": (_U64, [_P]),
+    "aesw_host_circuit_num_regions": (_U64, [_P]),
+    "aesw_host_circuit_num_copies": (_U64, [_P]),
+    "aesw_host_circuit_closure_calls": (_U64, [_P]),
+    "aesw_host_circuit_advice": (C.POINTER(C.c_uint8), [_P, _U32]),
+    "aesw_host_circuit_advice_assigned": (C.POINTER(C.c_uint8), [_P, _U32]),
+    "aesw_host_circuit_selector": (C.POINTER(C.c_uint8), [_P, _U32]),
+    "aesw_host_circuit_fixed": (C.POINTER(C.c_uint8), [_P]),
+    "aesw_host_circuit_table": (C.POINTER(C.c_uint8), [_P, _U32, C.POINTER(_U64)]),
+    "aesw_host_circuit_ciphertext": (_I, [_P, _U64, _P]),
+    "aesw_host_circuit_poke": (_I, [_P, _U32, _U64, C.c_uint8]),
+    "aesw_host_last_error": (C.c_char_p, []),
 }
 
 _lib = None
@@ -93,7 +116,7 @@ def load_library(path: Path | None = None) -> C.CDLL:
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no fallback implementation." % p)
     lib = C.CDLL(str(p))
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in list(SYMBOLS.items()) + list(HOST_SYMBOLS.items()):
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
@@ -150,6 +173,16 @@ def block_placement(k: int, n_sets: int, b: int):
 
 def block_capacity(k: int, n_sets: int) -> int:
     return int(load_library().aesw_block_capacity(k, n_sets))
+
+
+def selector_tags():
+    """(enc_tag[1360], key_tag[400], q_eq_rcon[96], rcon_fixed[96]): fixed selector data for keygen."""
+    e, k = np.zeros(K.AES_ROWS, np.uint8), np.zeros(K.KEY_ROWS, np.uint8)
+    q, c = np.zeros(K.WORDS_ROWS, np.uint8), np.zeros(K.WORDS_ROWS, np.uint8)
+    rc = load_library().aesw_selector_tags(_np_ptr(e), _np_ptr(k), _np_ptr(q), _np_ptr(c))
+    if rc:
+        raise AeswError(rc)
+    return e, k, q, c
 
 
 def device_count() -> int:
@@ -415,3 +448,91 @@ class Context:
         rc = self._lib.aesw_lookup_table(self._h, *[_np_ptr(t[i]) for i in range(4)])
         self._check(rc, "aesw_lookup_table")
         return t
+
+
+class HostCircuit:
+    """What the C++ host mirror's synthesize() assigned (include/aesw_host.h):
+    MockProver::run of the reference's circuits with device-fed value closures."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, C.c_void_p(handle)
+
+    @classmethod
+    def aes(cls, ctx: "Context", k: int, n_sets: int, key, pts, with_witnesses: bool = True,
+            skip_schedule_key: bool = False) -> "HostCircuit":
+        """load_enc_full_table, schedule_key(key), encrypt(pts[b]) for every block: TestAesCircuit /
+        Aes128BenchCircuit (src/aes128.rs:376-407, benches/aes128.rs:30-61)."""
+        key = np.ascontiguousarray(key, np.uint8).reshape(16)
+        pts = np.ascontiguousarray(pts, np.uint8).reshape(-1, 16)
+        h = C.c_void_p()
+        rc = ctx._lib.aesw_host_aes_circuit_run(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0],
+                                                1 if with_witnesses else 0, 1 if skip_schedule_key else 0, C.byref(h))
+        if rc:
+            raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
+        return cls(ctx._lib, h.value)
+
+    @classmethod
+    def key_schedule(cls, ctx: "Context", k: int, key) -> "HostCircuit":
+        """key_schedule.rs TestCircuit (src/key_schedule.rs:245-320)."""
+        key = np.ascontiguousarray(key, np.uint8).reshape(16)
+        h = C.c_void_p()
+        rc = ctx._lib.aesw_host_key_circuit_run(ctx._h, k, _np_ptr(key), C.byref(h))
+        if rc:
+            raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
+        return cls(ctx._lib, h.value)
+
+    def close(self):
+        if self._h:
+            self._lib.aesw_host_circuit_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def verify(self):
+        """mock.assert_satisfied(): (0, "") or (AESW_ERR_UNSATISFIED, first failure)."""
+        buf = C.create_string_buffer(256)
+        rc = self._lib.aesw_host_circuit_verify(self._h, buf, 256)
+        return rc, buf.value.decode()
+
+    num_advice = property(lambda self: self._lib.aesw_host_circuit_num_advice(self._h))
+    num_selectors = property(lambda self: self._lib.aesw_host_circuit_num_selectors(self._h))
+    num_rows = property(lambda self: self._lib.aesw_host_circuit_num_rows(self._h))
+    num_regions = property(lambda self: self._lib.aesw_host_circuit_num_regions(self._h))
+    num_copies = property(lambda self: self._lib.aesw_host_circuit_num_copies(self._h))
+    closure_calls = property(lambda self: self._lib.aesw_host_circuit_closure_calls(self._h))
+
+    def _arr(self, p, n):
+        return np.ctypeslib.as_array(p, shape=(n,)).copy()
+
+    def advice(self, col):
+        return self._arr(self._lib.aesw_host_circuit_advice(self._h, col), self.num_rows)
+
+    def advice_assigned(self, col):
+        return self._arr(self._lib.aesw_host_circuit_advice_assigned(self._h, col), self.num_rows)
+
+    def selector(self, s):
+        return self._arr(self._lib.aesw_host_circuit_selector(self._h, s), self.num_rows)
+
+    def fixed(self):
+        return self._arr(self._lib.aesw_host_circuit_fixed(self._h), self.num_rows)
+
+    def table(self, col):
+        n = C.c_uint64()
+        p = self._lib.aesw_host_circuit_table(self._h, col, C.byref(n))
+        return self._arr(p, n.value)
+
+    def ciphertext(self, b):
+        ct = np.zeros(16, np.uint8)
+        rc = self._lib.aesw_host_circuit_ciphertext(self._h, b, _np_ptr(ct))
+        if rc:
+            raise AeswError(rc)
+        return ct
+
+    def poke(self, col, row, value):
+        rc = self._lib.aesw_host_circuit_poke(self._h, col, row, value)
+        if rc:
+            raise AeswError(rc)

@@ -232,6 +232,18 @@ int aesw_key_packed_index(int col, int32_t idx[AESW_KEY_ROWS]) {
     return AESW_OK;
 }
 
+int aesw_selector_tags(uint8_t enc_tag[AESW_AES_ROWS], uint8_t key_tag[AESW_KEY_ROWS], uint8_t q_eq_rcon[AESW_WORDS_ROWS],
+                       uint8_t rcon_fixed[AESW_WORDS_ROWS]) {
+    uint8_t e[AES_ROWS], k[KEY_ROWS], q[WORDS_ROWS], c[WORDS_ROWS];
+    encrypt_selector_tags(e);
+    key_selector_tags(k, q, c);
+    if (enc_tag) std::memcpy(enc_tag, e, sizeof e);
+    if (key_tag) std::memcpy(key_tag, k, sizeof k);
+    if (q_eq_rcon) std::memcpy(q_eq_rcon, q, sizeof q);
+    if (rcon_fixed) std::memcpy(rcon_fixed, c, sizeof c);
+    return AESW_OK;
+}
+
 // FixedAes128Config::aes_callable, src/aes128.rs:303-325: set 0 is charged
 // KEY_SCHEDULE_ROWS (1760) of its 2^K rows, every set holds whole 1360-row
 // blocks.  Rows: set 0 starts behind the 400 rows the key schedule really uses.

@@ -183,4 +183,39 @@ inline void key_assigned_mask(int col, uint8_t mask[KEY_ROWS]) {
     }
 }
 
+// Fixed data for keygen: which chip's selector is enabled on
+// each slab row, as the Tag of its lookup (src/table.rs:10-16): 0 none (plain
+// copy / assign regions), 1 U8 range, 2 Xor, 3 Sbox, 4 GfMul2, 5 GfMul3.
+inline void encrypt_selector_tags(uint8_t tag[AES_ROWS]) {
+    for (int r = 0; r < AES_ROWS; ++r) tag[r] = 0;
+    for (int i = 0; i < 16; ++i) tag[16 + i] = 2;
+    for (int R = 1; R <= 9; ++R) {
+        const int B = 32 + 144 * (R - 1);
+        for (int i = 0; i < 16; ++i) tag[B + i] = 3;
+        for (int k = 0; k < 16; ++k) {
+            const int m = k & 3;
+            for (int t = 0; t < 4; ++t) tag[B + 16 + 7 * k + t] = MIX[m][t] == 1 ? 0 : (MIX[m][t] == 2 ? 4 : 5);
+            for (int t = 4; t < 7; ++t) tag[B + 16 + 7 * k + t] = 2;
+        }
+        for (int i = 0; i < 16; ++i) tag[B + 128 + i] = 2;
+    }
+    for (int i = 0; i < 16; ++i) tag[1328 + i] = 3;
+    for (int i = 0; i < 16; ++i) tag[1344 + i] = 2;
+}
+
+// Key slab rows, plus words_column: rcon[r] = round constant where q_eq_rcon is
+// enabled (row 20 + 8*(rho-1), src/key_schedule.rs:161-175), 0 elsewhere.
+inline void key_selector_tags(uint8_t tag[KEY_ROWS], uint8_t q_eq_rcon[WORDS_ROWS], uint8_t rcon_fixed[WORDS_ROWS]) {
+    for (int r = 0; r < WORDS_ROWS; ++r) q_eq_rcon[r] = rcon_fixed[r] = 0;
+    constexpr uint8_t RC[10] = {1, 2, 4, 8, 16, 32, 64, 128, 27, 54};
+    for (int rho = 0; rho < 10; ++rho) {
+        const int B = 40 * rho;
+        for (int r = 0; r < 4; ++r) tag[B + r] = 3;
+        for (int r = 4; r < 24; ++r) tag[B + r] = 2;
+        for (int r = 24; r < 40; ++r) tag[B + r] = 1;
+        q_eq_rcon[20 + 8 * rho] = 1;
+        rcon_fixed[20 + 8 * rho] = RC[rho];
+    }
+}
+
 }  // namespace aesw

@@ -1,0 +1,472 @@
+// aes_gadget.hpp -- host-side mirror of the reference's interface for the hot
+// path, in C++ (no Rust toolchain in this image): same type and method names,
+// argument meaning and error behaviour as
+//   src/chips/{u8_xor,sbox,gf_mul,u8_range_check}_chip.rs
+//   src/key_schedule.rs  (Aes128KeyScheduleConfig)
+//   src/aes128.rs        (FixedAes128Config<K,N>)
+//   src/table.rs         (load_enc_full_table)
+// with ONE difference, the point of the whole exercise: every value closure is a
+// pure read of a witness buffer that the device filled through the C ABI
+// (include/aesw.h), instead of recomputing xor_bytes / sub_byte / MUL_BY_n per
+// row.  configure(), selectors, lookups, region structure, copy constraints and
+// the aes_callable() bookkeeping are the reference's.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <memory>
+
+#include "../../include/aesw.h"
+#include "halo2_lite.hpp"
+
+namespace aesw {
+namespace host {
+
+// src/table.rs:10-16
+enum class Tag : Fp { U8 = 1, Xor = 2, Sbox = 3, GfMul2 = 4, GfMul3 = 5 };
+
+constexpr uint64_t AES_ROWS_ = AESW_AES_ROWS;                    // src/constant.rs:114
+constexpr uint64_t KEY_SCHEDULE_ROWS_ = AESW_KEY_SCHEDULE_ROWS;  // src/constant.rs:113
+
+// The device-computed witness of one circuit: key slab + n encrypt slabs (dense
+// layout).  Computed once, read by every synthesize() pass (keygen_vk,
+// keygen_pk, create_proof all re-run synthesize: SURVEY 3.1).
+struct AesWitness {
+    uint64_t n = 0;
+    uint8_t key[16] = {0};
+    std::vector<uint8_t> pt;                        // n*16
+    std::vector<uint8_t> x, y, z;                   // n*1360 each
+    std::vector<uint8_t> key_w, key_x, key_y, key_z;  // 96, 400, 400, 400
+
+    // aesw_schedule_key + aesw_encrypt_witness (host-pointer entry points).
+    static std::shared_ptr<const AesWitness> generate(aesw_ctx *ctx, const uint8_t key[16], const uint8_t *pts, uint64_t n) {
+        auto w = std::make_shared<AesWitness>();
+        w->n = n;
+        std::memcpy(w->key, key, 16);
+        w->pt.assign(pts, pts + 16 * n);
+        w->x.resize(n * AES_ROWS_); w->y.resize(n * AES_ROWS_); w->z.resize(n * AES_ROWS_);
+        w->key_w.resize(AESW_WORDS_ROWS); w->key_x.resize(AESW_KEY_ROWS); w->key_y.resize(AESW_KEY_ROWS); w->key_z.resize(AESW_KEY_ROWS);
+        aesw_key_slab ks{w->key_w.data(), w->key_x.data(), w->key_y.data(), w->key_z.data()};
+        int rc = aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks);
+        if (rc == AESW_OK && n)
+            rc = aesw_encrypt_witness(ctx, pts, nullptr, 0, n, AESW_LAYOUT_DENSE, w->x.data(), w->y.data(), w->z.data(), nullptr, nullptr);
+        if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("device witness generation failed: ") + aesw_strerror(rc));
+        return w;
+    }
+};
+
+// Where the gadget currently is inside a slab: three column arrays and a row.
+struct WitnessCursor {
+    const uint8_t *x = nullptr, *y = nullptr, *z = nullptr;
+    uint64_t row = 0, rows = 0;
+    void expect_x(uint64_t r, Fp v, const char *what) const {
+        // copy_advice carries the source cell's value; the device's x/y byte for the same cell must agree
+        if (r >= rows || x[r] != v) throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what);
+    }
+    void expect_y(uint64_t r, Fp v, const char *what) const {
+        if (r >= rows || y[r] != v) throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what);
+    }
+};
+
+// ---- src/chips/u8_range_check_chip.rs ---------------------------------------
+struct U8RangeCheckConfig { Column x; Selector q; };
+class U8RangeCheckChip {
+public:
+    static U8RangeCheckChip construct(U8RangeCheckConfig c, WitnessCursor *cur) { return U8RangeCheckChip{c, cur}; }
+    static U8RangeCheckConfig configure(ConstraintSystem &meta, Column x_col, Selector selector, TableColumn tag_tab, TableColumn value_tab) {
+        meta.lookup(Lookup{"Range check u8 value", selector, (Fp)Tag::U8, {x_col}, {tag_tab, value_tab}});  // :34-42
+        return U8RangeCheckConfig{x_col, selector};
+    }
+    void range_check(Layouter &layouter, const AssignedCell &x) const {  // :51-70
+        const uint64_t r = cur->row;
+        layouter.assign_region<int>("", [&](Region &region) {
+            region.enable_selector(config.q, 0);
+            x.copy_advice(region, config.x, 0);
+            return 0;
+        });
+        if (x.val.known) cur->expect_x(r, x.val.v, "range_check x");
+        cur->row++;
+    }
+    U8RangeCheckConfig config;
+    WitnessCursor *cur;
+};
+
+// ---- src/chips/u8_xor_chip.rs ------------------------------------------------
+struct U8XorConfig { Column x, y, z; Selector q; };
+class U8XorChip {
+public:
+    static U8XorChip construct(U8XorConfig c, WitnessCursor *cur) { return U8XorChip{c, cur}; }
+    static U8XorConfig configure(ConstraintSystem &meta, Column x_col, Column y_col, Column z_col, Selector selector,
+                                 TableColumn tag_tab, TableColumn x_tab, TableColumn y_tab, TableColumn z_tab) {
+        meta.lookup(Lookup{"Check correct XOR of u8 values", selector, (Fp)Tag::Xor, {x_col, y_col, z_col}, {tag_tab, x_tab, y_tab, z_tab}});  // :41-53
+        return U8XorConfig{x_col, y_col, z_col, selector};
+    }
+    AssignedCell xor_(Layouter &layouter, const AssignedCell &x, const AssignedCell &y) const {  // :63-100
+        const uint64_t r = cur->row;
+        const WitnessCursor *c = cur;
+        AssignedCell z = layouter.assign_region<AssignedCell>("", [&](Region &region) {
+            region.enable_selector(config.q, 0);
+            x.copy_advice(region, config.x, 0);
+            y.copy_advice(region, config.y, 0);
+            // was: xor_bytes(x_copied.value, y_copied.value) (:85-95) -- now the device's byte
+            return region.assign_advice(config.z, 0, [c, r] { return Value::of(c->z[r]); });
+        });
+        if (x.val.known) cur->expect_x(r, x.val.v, "xor x");
+        if (y.val.known) cur->expect_y(r, y.val.v, "xor y");
+        cur->row++;
+        return z;
+    }
+    U8XorConfig config;
+    WitnessCursor *cur;
+};
+
+// ---- src/chips/sbox_chip.rs ---------------------------------------------------
+struct SboxConfig { Column x, y; Selector q; };
+class SboxChip {
+public:
+    static SboxChip construct(SboxConfig c, WitnessCursor *cur) { return SboxChip{c, cur}; }
+    static SboxConfig configure(ConstraintSystem &meta, Column x_col, Column y_col, Selector selector, TableColumn tag_tab,
+                                TableColumn x_tab, TableColumn y_tab) {
+        meta.lookup(Lookup{"Check correct Sbox substitution", selector, (Fp)Tag::Sbox, {x_col, y_col}, {tag_tab, x_tab, y_tab}});  // :38-48
+        return SboxConfig{x_col, y_col, selector};
+    }
+    AssignedCell substitute(Layouter &layouter, const AssignedCell &x) const {  // :57-83
+        const uint64_t r = cur->row;
+        const WitnessCursor *c = cur;
+        AssignedCell y = layouter.assign_region<AssignedCell>("", [&](Region &region) {
+            region.enable_selector(config.q, 0);
+            x.copy_advice(region, config.x, 0);
+            // was: sub_byte(x_copied.value) (:73-78)
+            return region.assign_advice(config.y, 0, [c, r] { return Value::of(c->y[r]); });
+        });
+        if (x.val.known) cur->expect_x(r, x.val.v, "sbox x");
+        cur->row++;
+        return y;
+    }
+    SboxConfig config;
+    WitnessCursor *cur;
+};
+
+// ---- src/chips/gf_mul_chip.rs (macro instantiated for 2 and 3) -----------------
+struct MulConfig { Column x, y; Selector q; };
+template <int N>
+class MulByChip {
+public:
+    static MulByChip construct(MulConfig c, WitnessCursor *cur) { return MulByChip{c, cur}; }
+    static MulConfig configure(ConstraintSystem &meta, Column x_col, Column y_col, Selector selector, TableColumn tag_tab,
+                               TableColumn x_tab, TableColumn y_tab) {
+        meta.lookup(Lookup{N == 2 ? "Check correct gf mul by 2" : "Check correct gf mul by 3", selector,
+                           (Fp)(N == 2 ? Tag::GfMul2 : Tag::GfMul3), {x_col, y_col}, {tag_tab, x_tab, y_tab}});  // :38-48
+        return MulConfig{x_col, y_col, selector};
+    }
+    AssignedCell mul(Layouter &layouter, const AssignedCell &x) const {  // :59-89
+        const uint64_t r = cur->row;
+        const WitnessCursor *c = cur;
+        AssignedCell y = layouter.assign_region<AssignedCell>("", [&](Region &region) {
+            region.enable_selector(config.q, 0);
+            x.copy_advice(region, config.x, 0);
+            // was: Fp::from($dict[x]) (:75-84)
+            return region.assign_advice(config.y, 0, [c, r] { return Value::of(c->y[r]); });
+        });
+        if (x.val.known) cur->expect_x(r, x.val.v, "gf mul x");
+        cur->row++;
+        return y;
+    }
+    MulConfig config;
+    WitnessCursor *cur;
+};
+using MulBy2Chip = MulByChip<2>;
+using MulBy3Chip = MulByChip<3>;
+
+// ---- src/table.rs:18-192 --------------------------------------------------------
+// The four table columns come from the device (aesw_lookup_table), 66561 rows.
+inline void load_enc_full_table(Layouter &layouter, const TableColumn tables[4], aesw_ctx *ctx) {
+    std::vector<uint8_t> t[4];
+    for (auto &c : t) c.resize(AESW_TABLE_ROWS);
+    const int rc = aesw_lookup_table(ctx, t[0].data(), t[1].data(), t[2].data(), t[3].data());
+    if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("aesw_lookup_table: ") + aesw_strerror(rc));
+    layouter.assign_table("Assign full table", [&](Table &table) {
+        for (int c = 0; c < 4; ++c)
+            for (uint64_t row = 0; row < AESW_TABLE_ROWS; ++row) table.assign_cell(tables[c], row, t[c][row]);
+    });
+}
+
+// ---- src/key_schedule.rs ----------------------------------------------------------
+class Aes128KeyScheduleConfig {
+public:
+    // :40-77
+    static Aes128KeyScheduleConfig configure(ConstraintSystem &meta, const Column advices[3], U8XorConfig u8_xor_config,
+                                             SboxConfig sbox_config, U8RangeCheckConfig u8_range_check_config) {
+        Aes128KeyScheduleConfig c;
+        c.words_column = meta.advice_column();
+        c.round_constants = meta.fixed_column();
+        c.q_eq_rcon = meta.selector();
+        for (int i = 0; i < 3; ++i) meta.enable_equality(advices[i]);
+        meta.enable_equality(c.words_column);
+        meta.enable_constant(c.round_constants);
+        meta.create_gate(Gate{"Equality RC", c.q_eq_rcon, c.words_column, c.round_constants});  // q * (x - c), :59-64
+        c.u8_range_check_config = u8_range_check_config;
+        c.u8_xor_config = u8_xor_config;
+        c.sbox_config = sbox_config;
+        return c;
+    }
+
+    void attach_witness(std::shared_ptr<const AesWitness> w) { wit = std::move(w); }
+
+    // :80-96
+    std::vector<std::vector<AssignedCell>> schedule_keys(Layouter &layouter, const uint8_t key[16]) {
+        if (!wit) throw Error(Error::Synthesis, "no device witness attached");
+        if (std::memcmp(key, wit->key, 16) != 0) throw Error(Error::Mismatch, "key differs from the key the device witness was generated for");
+        chip_cur = WitnessCursor{wit->key_x.data(), wit->key_y.data(), wit->key_z.data(), 0, AESW_KEY_ROWS};
+        words_row = 0;
+        std::vector<std::vector<AssignedCell>> words;
+        std::vector<AssignedCell> round = assign_first_round(layouter);
+        words.push_back(round);
+        for (uint32_t i = 1; i <= 10; ++i) {
+            round = assign_round(layouter, i, round);
+            words.push_back(round);
+        }
+        return words;
+    }
+
+    Column words_column, round_constants;
+    Selector q_eq_rcon;
+    U8RangeCheckConfig u8_range_check_config;
+    U8XorConfig u8_xor_config;
+    SboxConfig sbox_config;
+
+private:
+    // :98-118 -- was Fp::from(byte as u64) of the key literal (:112), now words_column's device bytes
+    std::vector<AssignedCell> assign_first_round(Layouter &layouter) {
+        const uint8_t *w = wit->key_w.data();
+        auto out = layouter.assign_region<std::vector<AssignedCell>>("Assign first four words", [&](Region &region) {
+            std::vector<AssignedCell> words;
+            for (uint64_t i = 0; i < 16; ++i) words.push_back(region.assign_advice(words_column, i, [w, i] { return Value::of(w[i]); }));
+            return words;
+        });
+        words_row = 16;
+        return out;
+    }
+
+    // :122-224
+    std::vector<AssignedCell> assign_round(Layouter &layouter, uint32_t round, const std::vector<AssignedCell> &prev_round_bytes) {
+        const U8XorChip xor_chip = U8XorChip::construct(u8_xor_config, &chip_cur);
+        const SboxChip sbox_chip = SboxChip::construct(sbox_config, &chip_cur);
+        const U8RangeCheckChip range_chip = U8RangeCheckChip::construct(u8_range_check_config, &chip_cur);
+        const uint8_t *w = wit->key_w.data();
+        // :141-154 shift previous round: copy bytes 13,14,15,12 into words_column
+        const uint64_t r0 = words_row;
+        auto shifted = layouter.assign_region<std::vector<AssignedCell>>("shift previous round", [&](Region &region) {
+            static const size_t rot[4] = {13, 14, 15, 12};
+            std::vector<AssignedCell> v;
+            for (uint64_t i = 0; i < 4; ++i) v.push_back(prev_round_bytes[rot[i]].copy_advice(region, words_column, i));
+            return v;
+        });
+        for (int i = 0; i < 4; ++i)
+            if (shifted[i].val.known && w[r0 + i] != shifted[i].val.v) throw Error(Error::Mismatch, "words_column shift bytes");
+        words_row += 4;
+        // :156-159
+        std::vector<AssignedCell> subbed;
+        for (const auto &b : shifted) subbed.push_back(sbox_chip.substitute(layouter, b));
+        // :161-187 "Assign rc": the rcon and three zero pads, read from the device's words_column bytes
+        const uint64_t r1 = words_row;
+        const Fp rc = ROUND_CONSTANT(round - 1);  // fixed column value stays a host constant (src/utils.rs:28)
+        auto rc_assigned = layouter.assign_region<std::vector<AssignedCell>>("Assign rc", [&](Region &region) {
+            std::vector<AssignedCell> res;
+            region.enable_selector(q_eq_rcon, 0);
+            region.assign_fixed(round_constants, 0, [rc] { return Value::of(rc); });
+            for (uint64_t i = 0; i < 4; ++i) res.push_back(region.assign_advice(words_column, i, [w, r1, i] { return Value::of(w[r1 + i]); }));
+            return res;
+        });
+        words_row += 4;
+        // :189-194
+        std::vector<AssignedCell> rconned;
+        for (int i = 0; i < 4; ++i) rconned.push_back(xor_chip.xor_(layouter, subbed[i], rc_assigned[i]));
+        // :197-204
+        std::vector<AssignedCell> next_word, words;
+        for (int i = 0; i < 4; ++i) next_word.push_back(xor_chip.xor_(layouter, prev_round_bytes[i], rconned[i]));
+        words = next_word;
+        // :207-216
+        for (int i = 1; i < 4; ++i) {
+            std::vector<AssignedCell> nw;
+            for (int j = 0; j < 4; ++j) nw.push_back(xor_chip.xor_(layouter, prev_round_bytes[i * 4 + j], next_word[j]));
+            next_word = nw;
+            words.insert(words.end(), nw.begin(), nw.end());
+        }
+        // :218-221
+        for (const auto &b : words) range_chip.range_check(layouter, b);
+        return words;
+    }
+
+    static Fp ROUND_CONSTANT(uint32_t i) {  // src/utils.rs:28
+        static const Fp rc[10] = {1, 2, 4, 8, 16, 32, 64, 128, 27, 54};
+        return rc[i];
+    }
+
+    std::shared_ptr<const AesWitness> wit;
+    WitnessCursor chip_cur;
+    uint64_t words_row = 0;
+};
+
+// ---- src/aes128.rs -------------------------------------------------------------------
+// FixedAes128Config<K, N>: K and N are runtime members here (const generics in the reference).
+class FixedAes128Config {
+public:
+    // :46-141
+    static FixedAes128Config configure(ConstraintSystem &meta, uint32_t K, uint32_t N) {
+        FixedAes128Config c;
+        c.K = K;
+        c.N = N;
+        for (int i = 0; i < 4; ++i) c.tables[i] = meta.lookup_table_column();  // first is the tag column
+        c.advices.resize(N);
+        for (uint32_t i = 0; i < N; ++i)
+            for (int j = 0; j < 3; ++j) c.advices[i][j] = meta.advice_column();
+        for (uint32_t i = 0; i < N; ++i) {
+            const Selector q_u8_range_check = meta.complex_selector();
+            const Selector q_u8_xor = meta.complex_selector();
+            const Selector q_sbox = meta.complex_selector();
+            const Selector q_mul_by_2 = meta.complex_selector();
+            const Selector q_mul_by_3 = meta.complex_selector();
+            const auto &a = c.advices[i];
+            c.range_configs.push_back(U8RangeCheckChip::configure(meta, a[0], q_u8_range_check, c.tables[0], c.tables[1]));
+            c.xor_configs.push_back(U8XorChip::configure(meta, a[0], a[1], a[2], q_u8_xor, c.tables[0], c.tables[1], c.tables[2], c.tables[3]));
+            c.sbox_configs.push_back(SboxChip::configure(meta, a[0], a[1], q_sbox, c.tables[0], c.tables[1], c.tables[2]));
+            c.mul2_configs.push_back(MulBy2Chip::configure(meta, a[0], a[1], q_mul_by_2, c.tables[0], c.tables[1], c.tables[2]));
+            c.mul3_configs.push_back(MulBy3Chip::configure(meta, a[0], a[1], q_mul_by_3, c.tables[0], c.tables[1], c.tables[2]));
+        }
+        c.key_schedule_config = Aes128KeyScheduleConfig::configure(meta, c.advices[0].data(), c.xor_configs[0], c.sbox_configs[0], c.range_configs[0]);
+        for (const auto &v : c.advices)
+            for (const auto &col : v) meta.enable_equality(col);
+        return c;
+    }
+
+    void attach_witness(std::shared_ptr<const AesWitness> w) {
+        wit = w;
+        key_schedule_config.attach_witness(std::move(w));
+    }
+
+    // :143-152
+    void schedule_key(Layouter &layouter, const uint8_t key[16]) {
+        keys = key_schedule_config.schedule_keys(layouter, key);
+        have_keys = true;
+    }
+
+    // :154-265
+    std::vector<AssignedCell> encrypt(Layouter &layouter, const uint8_t plaintext[16]) {
+        if (!aes_callable()) throw Panic(Panic::Capacity, "AES calls too many. doesn't fit in the rows");  // :159-162
+        count += 1;
+        if (!have_keys) throw Panic(Panic::NoKey, "Keys should be scheduled");  // :170
+        if (!wit) throw Error(Error::Synthesis, "no device witness attached");
+        const uint64_t b = total++;  // the b-th encrypt() call reads slab b
+        if (b >= wit->n) throw Error(Error::Mismatch, "more encrypt() calls than blocks in the device witness");
+        if (std::memcmp(plaintext, wit->pt.data() + 16 * b, 16) != 0) throw Error(Error::Mismatch, "plaintext differs from the device witness's block");
+        cur = WitnessCursor{wit->x.data() + b * AES_ROWS_, wit->y.data() + b * AES_ROWS_, wit->z.data() + b * AES_ROWS_, 0, AES_ROWS_};
+
+        const U8XorChip xor_chip = U8XorChip::construct(xor_config(), &cur);
+        const SboxChip sbox_chip = SboxChip::construct(sbox_config(), &cur);
+        const Column *adv = get_advices();
+        const WitnessCursor *c = &cur;
+
+        // :176-192 "Assign plaintext" -- was Fp::from(p as u64) of the literal (:187)
+        auto assigned_plaintext = layouter.assign_region<std::vector<AssignedCell>>("Assign plaintext", [&](Region &region) {
+            std::vector<AssignedCell> v;
+            for (uint64_t i = 0; i < 16; ++i) v.push_back(region.assign_advice(adv[0], i, [c, i] { return Value::of(c->x[i]); }));
+            return v;
+        });
+        cur.row = 16;
+        // :194-198
+        std::vector<AssignedCell> prev_round;
+        for (int i = 0; i < 16; ++i) prev_round.push_back(xor_chip.xor_(layouter, assigned_plaintext[i], keys[0][i]));
+
+        static const uint32_t matrix[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};  // :228-233
+        for (int no_round = 1; no_round < 11; ++no_round) {
+            std::vector<std::vector<AssignedCell>> subbed(4);  // :203-209
+            for (int i = 0; i < 16; ++i) subbed[i / 4].push_back(sbox_chip.substitute(layouter, prev_round[i]));
+            std::vector<std::vector<AssignedCell>> shifted(4);  // :216-223
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) shifted[i].push_back(subbed[(i + j) % 4][j]);
+            std::vector<std::vector<AssignedCell>> mixed;  // :236-248
+            if (no_round == 10) {
+                mixed = shifted;
+            } else {
+                for (const auto &word : shifted) {
+                    std::vector<AssignedCell> col;
+                    for (const auto &coeffs : matrix) col.push_back(lcon(layouter, word, coeffs));
+                    mixed.push_back(col);
+                }
+            }
+            std::vector<AssignedCell> next;  // :250-261
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) next.push_back(xor_chip.xor_(layouter, mixed[i][j], keys[no_round][i * 4 + j]));
+            prev_round = next;
+        }
+        if (cur.row != AES_ROWS_) throw Error(Error::Synthesis, "a block must use exactly AES_ROWS rows");
+        return prev_round;
+    }
+
+    Aes128KeyScheduleConfig key_schedule_config;
+    std::vector<std::array<Column, 3>> advices;
+    TableColumn tables[4];
+    uint32_t K = 0, N = 0;
+
+private:
+    // :268-301
+    AssignedCell lcon(Layouter &layouter, const std::vector<AssignedCell> &word, const uint32_t coeffs[4]) {
+        const U8XorChip xor_chip = U8XorChip::construct(xor_config(), &cur);
+        const MulBy2Chip mul2_chip = MulBy2Chip::construct(mul2_config(), &cur);
+        const MulBy3Chip mul3_chip = MulBy3Chip::construct(mul3_config(), &cur);
+        const Column *adv = get_advices();
+        std::vector<AssignedCell> tmp;
+        for (int t = 0; t < 4; ++t) {
+            switch (coeffs[t]) {
+            case 1: {  // :279-288 just copy advice from word
+                const uint64_t r = cur.row;
+                tmp.push_back(layouter.assign_region<AssignedCell>("", [&](Region &region) { return word[t].copy_advice(region, adv[0], 0); }));
+                if (word[t].val.known) cur.expect_x(r, word[t].val.v, "lcon copy");
+                cur.row++;
+                break;
+            }
+            case 2: tmp.push_back(mul2_chip.mul(layouter, word[t])); break;
+            case 3: tmp.push_back(mul3_chip.mul(layouter, word[t])); break;
+            default: throw Panic(Panic::Other, "col should be 1, 2, or 3.");  // :294
+            }
+        }
+        const AssignedCell inter_1 = xor_chip.xor_(layouter, tmp[0], tmp[1]);
+        const AssignedCell inter_2 = xor_chip.xor_(layouter, tmp[2], tmp[3]);
+        return xor_chip.xor_(layouter, inter_1, inter_2);
+    }
+
+    // :303-325
+    bool aes_callable() {
+        uint64_t max_row = (uint64_t)1 << K;
+        if (current == 0) max_row -= KEY_SCHEDULE_ROWS_;
+        if (max_row >= count * AES_ROWS_ + AES_ROWS_) return true;
+        if (current < N - 1) {
+            current += 1;
+            count = 0;
+            return true;
+        }
+        return false;
+    }
+    // :328-356 config getters
+    U8XorConfig xor_config() const { return xor_configs.at(current); }
+    SboxConfig sbox_config() const { return sbox_configs.at(current); }
+    MulConfig mul2_config() const { return mul2_configs.at(current); }
+    MulConfig mul3_config() const { return mul3_configs.at(current); }
+    const Column *get_advices() const { return advices.at(current).data(); }
+
+    std::vector<U8RangeCheckConfig> range_configs;
+    std::vector<U8XorConfig> xor_configs;
+    std::vector<SboxConfig> sbox_configs;
+    std::vector<MulConfig> mul2_configs, mul3_configs;
+    std::vector<std::vector<AssignedCell>> keys;
+    bool have_keys = false;
+    uint32_t current = 0;  // which column set is in use
+    uint64_t count = 0;    // AES calls in the current set
+    uint64_t total = 0;    // AES calls overall = slab index
+    std::shared_ptr<const AesWitness> wit;
+    WitnessCursor cur;
+};
+
+}  // namespace host
+}  // namespace aesw

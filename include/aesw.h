@@ -107,6 +107,13 @@ int aesw_key_packed_index(int col, int32_t idx[AESW_KEY_ROWS]);
  * start behind the 400 key rows.  AESW_ERR_CAPACITY when the reference panics. */
 int aesw_block_placement(uint32_t k, uint32_t n_sets, uint64_t b, uint32_t *set, uint64_t *row);
 uint64_t aesw_block_capacity(uint32_t k, uint32_t n_sets);
+/* Fixed (input-independent) selector data for keygen: per slab row the Tag
+ * (src/table.rs:10-16: 1 U8, 2 Xor, 3 Sbox, 4 GfMul2, 5 GfMul3, 0 = no lookup)
+ * of the chip whose selector the reference enables there; for words_column the
+ * rows where q_eq_rcon is on and the round constant in the fixed column
+ * (src/key_schedule.rs:161-175).  Any output may be NULL. */
+int aesw_selector_tags(uint8_t enc_tag[AESW_AES_ROWS], uint8_t key_tag[AESW_KEY_ROWS],
+                       uint8_t q_eq_rcon[AESW_WORDS_ROWS], uint8_t rcon_fixed[AESW_WORDS_ROWS]);
 
 /* ---- device-pointer entry points (asynchronous on `stream`) -------------- */
 /* stream is a hipStream_t passed as void* (NULL = the default stream).

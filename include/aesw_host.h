@@ -1,0 +1,63 @@
+/*
+ * aesw_host.h -- C entry points of the host-side mirror of the reference's
+ * interface (halo2-aes_amd/host/: FixedAes128Config, Aes128KeyScheduleConfig,
+ * the four chips, load_enc_full_table on a minimal halo2-style front end).
+ *
+ * They run the reference's own circuits with every value closure reading the
+ * device witness obtained through include/aesw.h, then expose what
+ * synthesize() assigned, so the parity tests can read like the reference's:
+ *   aesw_host_aes_circuit_run  = MockProver::run(K, &TestAesCircuit / Aes128BenchCircuit)
+ *                                (src/aes128.rs:376-418, benches/aes128.rs:30-61)
+ *   aesw_host_key_circuit_run  = MockProver::run(K, &TestCircuit)   (src/key_schedule.rs:245-320, :385-392)
+ *   aesw_host_circuit_verify   = mock.assert_satisfied()
+ * Status codes are aesw_status (aesw.h): AESW_ERR_CAPACITY / AESW_ERR_NO_KEY
+ * where the reference panics, AESW_ERR_MISMATCH for plonk::Error::Synthesis
+ * raised because a host value disagrees with the device witness.
+ */
+#ifndef AESW_HOST_H
+#define AESW_HOST_H
+
+#include "aesw.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aesw_host_circuit aesw_host_circuit;
+
+/* load_enc_full_table, schedule_key(key), then encrypt(pts[b]) for b < n, in a
+ * FixedAes128Config<K, n_sets> circuit of 2^k rows.  with_witnesses = 0 mimics
+ * keygen (value closures are never evaluated).  skip_schedule_key = 1 omits
+ * schedule_key() to exercise the reference's expect("Keys should be scheduled"). */
+int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16],
+                              const uint8_t *pts, uint64_t n, int with_witnesses,
+                              int skip_schedule_key, aesw_host_circuit **out);
+/* key_schedule.rs TestCircuit: 3 advice columns + words_column, schedule_keys only. */
+int aesw_host_key_circuit_run(aesw_ctx *ctx, uint32_t k, const uint8_t key[16],
+                              aesw_host_circuit **out);
+void aesw_host_circuit_free(aesw_host_circuit *c);
+/* AESW_OK or AESW_ERR_UNSATISFIED (+ first failure in msg). */
+int aesw_host_circuit_verify(const aesw_host_circuit *c, char *msg, size_t msg_len);
+
+uint32_t aesw_host_circuit_num_advice(const aesw_host_circuit *c);
+uint32_t aesw_host_circuit_num_selectors(const aesw_host_circuit *c);
+uint64_t aesw_host_circuit_num_rows(const aesw_host_circuit *c);
+uint64_t aesw_host_circuit_num_regions(const aesw_host_circuit *c);
+uint64_t aesw_host_circuit_num_copies(const aesw_host_circuit *c);
+uint64_t aesw_host_circuit_closure_calls(const aesw_host_circuit *c);
+const uint8_t *aesw_host_circuit_advice(const aesw_host_circuit *c, uint32_t col);
+const uint8_t *aesw_host_circuit_advice_assigned(const aesw_host_circuit *c, uint32_t col);
+const uint8_t *aesw_host_circuit_selector(const aesw_host_circuit *c, uint32_t sel);
+const uint8_t *aesw_host_circuit_fixed(const aesw_host_circuit *c);
+const uint8_t *aesw_host_circuit_table(const aesw_host_circuit *c, uint32_t col, uint64_t *rows);
+/* values of the cells encrypt() returned for block b */
+int aesw_host_circuit_ciphertext(const aesw_host_circuit *c, uint64_t b, uint8_t ct[16]);
+/* test hook: overwrite one advice cell */
+int aesw_host_circuit_poke(aesw_host_circuit *c, uint32_t col, uint64_t row, uint8_t value);
+/* text of the failure of the last *_run call on this thread ("" if none) */
+const char *aesw_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

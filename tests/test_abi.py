@@ -13,8 +13,8 @@ import oracle_lib as ol
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _declared():
-    text = (ROOT / "include" / "aesw.h").read_text()
+def _declared(header="aesw.h"):
+    text = (ROOT / "include" / header).read_text()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(aesw_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,9 +26,11 @@ def test_every_declared_symbol_is_exported(pkg):
     for n in names:
         assert hasattr(lib, n), "libaesw.so does not export %s" % n
     assert sorted(pkg.api.SYMBOLS) == names, "api.py binds a different set than include/aesw.h declares"
+    host_names = _declared("aesw_host.h")
+    assert sorted(pkg.api.HOST_SYMBOLS) == host_names, "api.py binds a different set than include/aesw_host.h declares"
     out = subprocess.run(["nm", "-D", "--defined-only", str(pkg.api.LIB_PATH)], stdout=subprocess.PIPE, text=True).stdout
     exported = set(re.findall(r" T (aesw_\w+)", out))
-    assert set(names) <= exported
+    assert set(names) <= exported and set(host_names) <= exported
 
 
 def test_library_is_gfx950_code(pkg):
@@ -77,6 +79,30 @@ def test_block_placement_mirrors_aes_callable(pkg, oracle):
         for b in range(120):
             assert c.block_placement(b) == pkg.block_placement(16, 3, b)
     assert pkg.block_capacity(10, 2) == 0          # 2^10 < 1760: set 0 holds nothing, set 1 holds 0 (1024 < 1360)
+
+
+def test_selector_tags_match_oracle_circuit(pkg, oracle):
+    """Fixed selector data == the selectors the restated synthesize() enables (K=16, N=2)."""
+    enc, key, q, rc = pkg.selector_tags()
+    rng = np.random.default_rng(9)
+    with oracle.circuit(16, 2, rng.integers(0, 256, 16, dtype=np.uint8), rng.integers(0, 256, (50, 16), dtype=np.uint8),
+                        record_copies=False) as c:
+        n_sets = 2
+        for s in range(n_sets):
+            sel = {1: c.selector(5 * s + 0), 2: c.selector(5 * s + 1), 3: c.selector(5 * s + 2),
+                   4: c.selector(5 * s + 3), 5: c.selector(5 * s + 4)}
+            expect = np.zeros(c.num_rows, np.uint8)
+            if s == 0:
+                expect[:400] = key
+            for b in range(50):
+                bs, row = c.block_placement(b)
+                if bs == s:
+                    expect[row:row + 1360] = enc
+            for tag, col in sel.items():
+                assert np.array_equal(col, (expect == tag).astype(np.uint8)), "set %d tag %d" % (s, tag)
+        q_sel = c.selector(5 * n_sets)
+        assert np.array_equal(q_sel[:96], q) and not q_sel[96:].any()
+        assert np.array_equal(c.fixed()[:96], rc)
 
 
 def test_no_cpu_path(pkg):
