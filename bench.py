@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of a hipGraph")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to aesw_set_option")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo to rehearse on one GPU)")
     return ap.parse_args()
 
 
@@ -174,8 +175,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        if "AESW_BENCH_DEVICE" in os.environ:  # rehearsal: several ranks on one GPU (gloo only)
+            local_rank = int(os.environ["AESW_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
     dev = local_rank if world > 1 else 0
     torch.cuda.set_device(dev)
     ctx = pkg.Context(dev)
@@ -198,7 +204,7 @@ def main():
         wl = "2^%d blocks, per-block keys (+ key-schedule witness), %s advice columns" % (a.log2_blocks or 20, a.layout)
     wall, ms_launch, graphed = runner.run(a.steps, a.warmup, not a.no_graph, barrier)
     if dist is not None:
-        t = torch.tensor([wall, ms_launch], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, ms_launch], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, ms_launch = float(t[0]), float(t[1])
     total_blocks = n * world * a.steps
@@ -292,26 +298,43 @@ def main():
     elif rank == 0:
         line["cpu_baseline"] = None
     if dist is not None:
-        # optional exchange step, timed separately (never part of `value`): gather every rank's columns on rank 0
+        # optional exchange step, timed separately (never part of `value`): gather every rank's columns on
+        # rank 0.  A watchdog emits the headline line anyway if the exchange stalls.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["gather"] = {"error": "timed out after 120 s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(120.0, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             strides = [pkg.column_stride(layout, c) for c in range(3)]
             wset = runner.sets[0]
+            gcols = [wset.x, wset.y, wset.z] if a.backend == "nccl" else [c.cpu() for c in (wset.x, wset.y, wset.z)]
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            full = pkg.sharding.gather_columns([wset.x, wset.y, wset.z], [n] * world, strides, dst=0)
+            full = pkg.sharding.gather_columns(gcols, [n] * world, strides, dst=0)
             torch.cuda.synchronize()
             dist.barrier()
             dt = time.perf_counter() - t0
             if rank == 0:
                 line["gather"] = {"seconds": dt, "GBps_into_root": (world - 1) * n * sum(strides) / dt / 1e9,
-                                  "note": "RCCL send/recv of per-rank column ranges to rank 0, outside `value`"}
+                                  "note": "send/recv of per-rank column ranges to rank 0 (RCCL over xGMI with nccl), outside `value`"}
             del full
         except Exception as e:
             if rank == 0:
                 line["gather"] = {"error": str(e)}
-        dist.barrier()
-        dist.destroy_process_group()
+        dog.cancel()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
     if rank == 0:
         print(json.dumps(line))
 
