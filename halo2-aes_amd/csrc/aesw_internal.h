@@ -19,6 +19,7 @@ struct EncParams {
     uint8_t *ct;            // n*16 or null
     KeyOut key;             // per-block-key mode only
     uint64_t n;
+    uint32_t ngroups;       // block groups (16*waves blocks each); a workgroup strides over them
 };
 
 struct KeyParams {
@@ -31,7 +32,7 @@ struct KeyParams {
 
 // key mode: 0 = per-block keys, 1 = shared key expanded in the kernel, 2 = shared key scheduled earlier (p.rk)
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, bool nt,
-                          hipStream_t s);
+                          uint32_t max_groups_in_flight, hipStream_t s);
 hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool nt, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
 hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, hipStream_t s);

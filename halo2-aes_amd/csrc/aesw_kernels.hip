@@ -229,22 +229,25 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     constexpr int WAVE_LDS = enc_wave_lds<L>(PBK, KEMIT);
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane0 = tid & 63;
     const int wave = tid >> 6;
     const int waves = blockDim.x >> 6;
-    const int blk = lane >> 2, w = lane & 3;
+    const int w = lane0 & 3;
 
-    const uint32_t shared_rk = TAB_BYTES;                          // 176 B, KM_SHARED only
-    const uint32_t stage = TAB_BYTES + RKS_BYTES + wave * WAVE_LDS;  // this wave's slab
-    const uint32_t rk_w = stage + (WAVE_LDS - St::RK_BYTES_W);      // PBK only: tail of the slab
+    const uint32_t shared_rk = TAB_BYTES;                           // 176 B, KM_SHARED only
+    const uint32_t stage0 = TAB_BYTES + RKS_BYTES + wave * WAVE_LDS;  // this wave's slab
 
-    const uint64_t blk0 = ((uint64_t)blockIdx.x * waves + wave) * BPW;
-    const int64_t left = (int64_t)a.n - (int64_t)blk0;
-    const int nvalid = left >= BPW ? BPW : (left > 0 ? (int)left : 0);
-    const bool live = blk < nvalid;
-
-    // inputs first, so their latency hides behind the table load
-    const uint32_t ptw = live ? reinterpret_cast<const uint32_t *>(a.pt)[(blk0 + blk) * 4 + w] : 0u;
+    // the first group's inputs first, so their latency hides behind the table load
+    auto group_blk0 = [&](uint32_t grp) { return ((uint64_t)grp * waves + wave) * BPW; };
+    auto group_nvalid = [&](uint64_t b0) {
+        const int64_t left = (int64_t)a.n - (int64_t)b0;
+        return left >= BPW ? BPW : (left > 0 ? (int)left : 0);
+    };
+    uint32_t ptw_first = 0;
+    {
+        const uint64_t b0 = group_blk0(blockIdx.x);
+        if ((lane0 >> 2) < group_nvalid(b0)) ptw_first = reinterpret_cast<const uint32_t *>(a.pt)[(b0 + (lane0 >> 2)) * 4 + w];
+    }
     uint32_t rkr[11];  // KM_PRE: this lane's word of every round key
     if (KM == KM_PRE) {
 #pragma unroll
@@ -263,71 +266,88 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
             NullKSink ks;
             uint32_t k = kw;
             uint32_t *rks = reinterpret_cast<uint32_t *>(lds + shared_rk);
-            if (blk == 0) rks[w] = k;
+            if (lane0 < 4) rks[w] = k;
 #pragma unroll
             for (int rho = 1; rho <= 10; ++rho) {
                 k = key_round_dev<L>(ks, rho, w, k, tab);
-                if (blk == 0) rks[4 * rho + w] = k;
+                if (lane0 < 4) rks[4 * rho + w] = k;
             }
         }
         __syncthreads();
     }
-    if (nvalid == 0) return;
+    // A workgroup strides over block groups: with max_groups_in_flight = resident
+    // workgroups the table / round-key setup above is paid once per CU slot.
+    for (uint32_t grp = blockIdx.x; grp < a.ngroups; grp += gridDim.x) {
+        // Everything below is recomputed per group from these two opaque values: otherwise the
+        // compiler hoists ~200 loop-invariant LDS/flush addresses out of the loop and spills them.
+        int lane = lane0;
+        uint32_t stage = stage0;
+        asm volatile("" : "+v"(lane), "+v"(stage));
+        const int blk = lane >> 2;
+        const uint32_t rk_w = stage + (WAVE_LDS - St::RK_BYTES_W);  // PBK only: tail of the slab
+        const uint64_t blk0 = group_blk0(grp);
+        const int nvalid = group_nvalid(blk0);
+        if (nvalid == 0) continue;
+        const bool live = blk < nvalid;
+        const uint32_t ptw = grp == blockIdx.x ? ptw_first
+                             : (live ? reinterpret_cast<const uint32_t *>(a.pt)[(blk0 + blk) * 4 + w] : 0u);
+        if (grp != blockIdx.x) wave_lds_fence();  // the previous group's flush reads precede this group's writes
 
-    if (PBK) {
-        const uint32_t kw = live ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
-        key_phase<L, KEMIT>(lds, stage, rk_w, kw, blk, w, tab);
-        if (KEMIT) {
+        if (PBK) {
+            const uint32_t kw = live ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
+            key_phase<L, KEMIT>(lds, stage, rk_w, kw, blk, w, tab);
+            if (KEMIT) {
+                wave_lds_fence();
+                key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
+            }
             wave_lds_fence();
-            key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
         }
-        wave_lds_fence();
-    }
-    const uint32_t *rkp = PBK ? reinterpret_cast<const uint32_t *>(lds + rk_w) + blk * 44 + w
-                              : reinterpret_cast<const uint32_t *>(lds + shared_rk) + w;
-    auto rkw = [&](int r) -> uint32_t { return KM == KM_PRE ? rkr[r] : rkp[4 * r]; };
+        const uint32_t *rkp = PBK ? reinterpret_cast<const uint32_t *>(lds + rk_w) + blk * 44 + w
+                                  : reinterpret_cast<const uint32_t *>(lds + shared_rk) + w;
+        auto rkw = [&](int r) -> uint32_t { return KM == KM_PRE ? rkr[r] : rkp[4 * r]; };
 
-    DevSink<L> s;
-    s.lds = lds;
-    s.pb[0] = stage + St::OX + blk * St::SX + 4 * w;
-    s.pb[1] = stage + St::OY + blk * St::SY + 4 * w;
-    s.pb[2] = stage + St::OZ + blk * St::SZ + 4 * w;
-    s.mb[0] = stage + St::OX + blk * St::SX + G::X_MIXW * w;
-    s.mb[1] = stage + St::OY + blk * St::SY + G::Y_MIXW * w;
-    s.mb[2] = stage + St::OZ + blk * St::SZ + G::Z_MIXW * w;
+        DevSink<L> s;
+        s.lds = lds;
+        s.pb[0] = stage + St::OX + blk * St::SX + 4 * w;
+        s.pb[1] = stage + St::OY + blk * St::SY + 4 * w;
+        s.pb[2] = stage + St::OZ + blk * St::SZ + 4 * w;
+        s.mb[0] = stage + St::OX + blk * St::SX + G::X_MIXW * w;
+        s.mb[1] = stage + St::OY + blk * St::SY + G::Y_MIXW * w;
+        s.mb[2] = stage + St::OZ + blk * St::SZ + G::Z_MIXW * w;
 
-    uint8_t *gx = a.x + blk0 * G::XS;
-    uint8_t *gy = a.y + blk0 * G::YS;
-    uint8_t *gz = a.z + blk0 * G::ZS;
+        uint8_t *gx = a.x + blk0 * G::XS;
+        uint8_t *gy = a.y + blk0 * G::YS;
+        uint8_t *gz = a.z + blk0 * G::ZS;
 
-    auto round = [&](int relx, int rely, int relz, uint32_t st, uint32_t rkw) -> uint32_t {
-        const uint32_t sub = emit_sbox<L>(s, relx, rely, relz, st, tab);
-        const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
-        return emit_mix_ark<L>(s, relx, rely, relz, sh, rkw, tab);
-    };
-
-    // rows 0..31, then rounds 1..9 (+10); after each round the lines that just
-    // became complete are flushed.  Fully unrolled: R is a constant in every copy.
-    using WX = typename St::WX;
-    using WY = typename St::WY;
-    using WZ = typename St::WZ;
-    uint32_t st = emit_head<L>(s, ptw, rkw(0));
-#pragma unroll
-    for (int R = 1; R <= 9; ++R) {
-        st = round(WX::woff(R), WY::woff(R), WZ::woff(R), st, rkw(R));
-        if (R == 9) {
-            const uint32_t sub = emit_sbox<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), st, tab);
+        auto round = [&](int relx, int rely, int relz, uint32_t st, uint32_t rkw) -> uint32_t {
+            const uint32_t sub = emit_sbox<L>(s, relx, rely, relz, st, tab);
             const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
-            st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkw(10));
-        }
-        wave_lds_fence();
-        flush_lines<WX, NT>(R, lds, stage + St::OX, gx, nvalid, lane);
-        flush_lines<WY, NT>(R, lds, stage + St::OY, gy, nvalid, lane);
-        flush_lines<WZ, NT>(R, lds, stage + St::OZ, gz, nvalid, lane);
-        wave_lds_fence();
-    }
+            return emit_mix_ark<L>(s, relx, rely, relz, sh, rkw, tab);
+        };
 
-    if (a.ct && live) reinterpret_cast<uint32_t *>(a.ct)[(blk0 + blk) * 4 + w] = st;
+        // rows 0..31, then rounds 1..9 (+10); after each round the lines that just
+        // became complete are flushed.  Fully unrolled: R is a constant in every copy.
+        using WX = typename St::WX;
+        using WY = typename St::WY;
+        using WZ = typename St::WZ;
+        uint32_t st = emit_head<L>(s, ptw, rkw(0));
+    #pragma unroll
+        for (int R = 1; R <= 9; ++R) {
+            st = round(WX::woff(R), WY::woff(R), WZ::woff(R), st, rkw(R));
+            if (R == 9) {
+                const uint32_t sub = emit_sbox<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), st, tab);
+                const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
+                st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkw(10));
+            }
+            wave_lds_fence();
+            flush_lines<WX, NT>(R, lds, stage + St::OX, gx, nvalid, lane);
+            flush_lines<WY, NT>(R, lds, stage + St::OY, gy, nvalid, lane);
+            flush_lines<WZ, NT>(R, lds, stage + St::OZ, gz, nvalid, lane);
+            wave_lds_fence();
+        }
+
+        if (a.ct && live) reinterpret_cast<uint32_t *>(a.ct)[(blk0 + blk) * 4 + w] = st;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -411,41 +431,45 @@ __global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restric
 // launchers
 // ---------------------------------------------------------------------------
 template <int L, bool XT, int KM, bool KEMIT, bool NT>
-static hipError_t launch_enc(const EncParams &p, int waves, hipStream_t stream) {
+static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, hipStream_t stream) {
     const int bpg = waves * BPW;
-    const uint64_t groups = (p.n + bpg - 1) / bpg;
+    const uint64_t groups = (p0.n + bpg - 1) / bpg;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
+    EncParams p = p0;
+    p.ngroups = (uint32_t)groups;
+    const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
     const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KM == KM_PBK, KEMIT);
     auto k = encrypt_kernel<L, XT, KM, KEMIT, NT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)groups), dim3(waves * LANES), lds, stream, p);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(waves * LANES), lds, stream, p);
     return hipGetLastError();
 }
 
 template <int L, bool XT, int KM, bool KEMIT>
-static hipError_t launch_enc_nt(const EncParams &p, int waves, bool nt, hipStream_t s) {
-    return nt ? launch_enc<L, XT, KM, KEMIT, true>(p, waves, s) : launch_enc<L, XT, KM, KEMIT, false>(p, waves, s);
+static hipError_t launch_enc_nt(const EncParams &p, int waves, bool nt, uint32_t cap, hipStream_t s) {
+    return nt ? launch_enc<L, XT, KM, KEMIT, true>(p, waves, cap, s) : launch_enc<L, XT, KM, KEMIT, false>(p, waves, cap, s);
 }
 
 template <int L, bool XT>
-static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, bool nt, hipStream_t s) {
-    if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, s);
-    if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, s);
-    return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, s);
+static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, bool nt, uint32_t cap, hipStream_t s) {
+    if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, cap, s);
+    if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, cap, s);
+    return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, cap, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, cap, s);
 }
 
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, bool nt,
-                          hipStream_t s) {
+                          uint32_t max_groups_in_flight, hipStream_t s) {
     if (waves < 1 || waves > 4 || keymode < 0 || keymode > 2) return hipErrorInvalidValue;
+    const uint32_t cap = max_groups_in_flight;
     if (layout == DENSE)
-        return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, s)
-                  : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, s);
-    return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, s)
-              : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, s);
+        return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, s)
+                  : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, s);
+    return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, cap, s)
+              : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, cap, s);
 }
 
 template <int L, bool XT, bool NT>

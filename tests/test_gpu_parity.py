@@ -220,6 +220,47 @@ def test_schedule_key_then_encrypt(pkg, oracle, layout):
     c.close()
 
 
+@pytest.mark.parametrize("cap", [1, 3, 512])
+def test_group_striding(pkg, oracle, cap):
+    """grid_cap < number of block groups: every workgroup walks several groups, reusing its LDS windows."""
+    import torch
+    c = pkg.Context(0)
+    c.set_option("grid_cap", cap)
+    pt, keys = _inputs(1111)
+    for layout in (ol.DENSE, ol.PACKED):
+        for k_host in (keys[0], keys):
+            got = c.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(np.ascontiguousarray(k_host)).cuda(),
+                                    layout=layout, want_ct=True, key_slab=True)
+            torch.cuda.synchronize()
+            exp = oracle.encrypt_witness(pt, k_host, layout=layout)
+            for col in "xyz":
+                _cmp(col, getattr(got, col), getattr(exp, col))
+            _cmp("ct", got.ct, exp.ct)
+            kexp = oracle.key_schedule_witness(k_host, layout=layout)
+            for col in ("w", "kx", "ky", "kz"):
+                _cmp(col, getattr(got.key, col), getattr(kexp, col))
+    c.close()
+
+
+def test_unaligned_column_buffers(ctx, oracle):
+    """Column pointers need only 16-byte alignment (128 is just faster)."""
+    import torch
+    pt, keys = _inputs(200)
+    for layout in (ol.DENSE, ol.PACKED):
+        strides = ol.ENC_STRIDE[layout]
+        bufs = [torch.full((200 * s + 4096,), 0xCD, dtype=torch.uint8, device="cuda") for s in strides]
+        offs = (16, 48, 112)
+        import halo2_aes_amd as pkg
+        out = pkg.Witness(*[b[o:o + 200 * s] for b, o, s in zip(bufs, offs, strides)], None, None)
+        ctx.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(keys[0]).cuda(), layout=layout, out=out)
+        torch.cuda.synchronize()
+        exp = oracle.encrypt_witness(pt, keys[0], layout=layout)
+        for b, o, s, name in zip(bufs, offs, strides, "xyz"):
+            h = b.cpu().numpy()
+            assert np.array_equal(h[o:o + 200 * s], getattr(exp, name)), name
+            assert np.all(h[:o] == 0xCD) and np.all(h[o + 200 * s:] == 0xCD), "wrote outside the column buffer"
+
+
 def test_config1_single_block(ctx):
     """BASELINE config 0: one block, fixed zero key (benches/aes128.rs shape)."""
     import torch

@@ -19,9 +19,14 @@ log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 workload = sys.argv[2] if len(sys.argv) > 2 else "c1"
 layout = pkg.LAYOUT_PACKED if (len(sys.argv) <= 3 or sys.argv[3] == "packed") else pkg.LAYOUT_DENSE
 variants = []
-for nt in (0, 1):
-    for w in (4, 3, 2, 1):
-        variants.append({"nt_stores": nt, "waves_shared": w, "waves_pbk": w})
+if len(sys.argv) > 4 and sys.argv[4] == "cap":
+    for w in (4, 3, 2):
+        for cap in (0, 256 * (8 // w), 256 * (8 // w) * 3 // 2, 256 * (8 // w) // 2):
+            variants.append({"waves_shared": w, "waves_pbk": w, "grid_cap": cap})
+else:
+    for nt in (0, 1):
+        for w in (4, 3, 2, 1):
+            variants.append({"nt_stores": nt, "waves_shared": w, "waves_pbk": w})
 ctxs = []
 for v in variants:
     c = pkg.Context(0)
