@@ -148,3 +148,41 @@ def test_dense_2p20_shared_key_properties(ctx, pkg, oracle):
     kexp = oracle.key_schedule_witness(key.numpy(), layout=ol.DENSE)
     for c in ("w", "kx", "ky", "kz"):
         assert np.array_equal(getattr(kw, c).cpu().numpy(), getattr(kexp, c))
+
+
+def test_config4_2p24_blocks_one_gpu(ctx, pkg, oracle):
+    """BASELINE configs[3] is 2^24 blocks over 8 GPUs (2^21 each); one MI355X's 288 GB holds all 2^24
+    (50.7 GB of packed columns), so the whole batch is generated here in one launch and checked by
+    the size-independent slab relations chunk by chunk, plus a random sample against the oracle."""
+    import torch
+    n = 1 << 24
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 << 30:
+        pytest.skip("needs ~80 GB of free HBM")
+    g = torch.Generator(device="cuda").manual_seed(0xA35128 + 4)
+    dpt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+    key = torch.randint(0, 256, (16,), dtype=torch.uint8, device="cuda", generator=g)
+    ctx.schedule_key(key, layout=pkg.LAYOUT_PACKED, key_slab=False)
+    rk = ctx.key_schedule_witness(key, layout=pkg.LAYOUT_PACKED).rk
+    got = ctx.encrypt_witness(dpt, None, layout=pkg.LAYOUT_PACKED, want_ct=True)
+    torch.cuda.synchronize()
+    tables = pkg.reference_tables()
+    iy, iz = pkg.packed_index(1), pkg.packed_index(2)
+    chunk = 1 << 20
+    for c0 in range(0, n, chunk):
+        x = got.x[c0 * 1360:(c0 + chunk) * 1360].view(chunk, 1360)
+        y = _unpack(torch, got.y[c0 * 1056:(c0 + chunk) * 1056], iy, chunk, 1056)
+        z = _unpack(torch, got.z[c0 * 608:(c0 + chunk) * 608], iz, chunk, 608)
+        ct = _check_slab_relations(torch, pkg, x, y, z, dpt[c0:c0 + chunk], rk.expand(chunk, 176), *tables)
+        assert torch.equal(ct, got.ct[c0:c0 + chunk])
+        del x, y, z
+    sample = np.sort(np.random.default_rng(2).choice(n, 8192, replace=False))
+    ds = torch.from_numpy(sample).cuda()
+    exp = oracle.encrypt_witness(dpt[ds].cpu().numpy(), key.cpu().numpy(), layout=ol.PACKED, threads=16)
+    for name, stride in (("x", 1360), ("y", 1056), ("z", 608)):
+        col = getattr(got, name).view(n, stride)[ds].cpu().numpy().reshape(-1)
+        assert np.array_equal(col, getattr(exp, name)), name
+    # blocks at shard boundaries of an 8-rank split must be where sharding.shard_range says
+    for r in range(8):
+        lo, hi = pkg.sharding.shard_range(n, r, 8)
+        assert (lo, hi) == (r << 21, (r + 1) << 21)
