@@ -62,6 +62,7 @@ SYMBOLS = {
     "aesw_key_schedule_witness_device": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P, _P]),
     "aesw_lookup_table_device": (_I, [_P, _P, _P, _P, _P, _P]),
     "aesw_expand_fr_device": (_I, [_P, _P, _U64, _P, _P]),
+    "aesw_assemble_advice_device": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
     "aesw_encrypt_witness": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab)]),
     "aesw_key_schedule_witness": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P]),
     "aesw_lookup_table": (_I, [_P, _P, _P, _P, _P]),
@@ -401,6 +402,21 @@ class Context:
             out = torch.empty((n, 32), dtype=torch.uint8, device=self._dev())
         rc = self._lib.aesw_expand_fr_device(self._h, cells.data_ptr(), n, out.data_ptr(), self._stream())
         self._check(rc, "aesw_expand_fr_device")
+        return out
+
+    def assemble_advice(self, k: int, n_sets: int, witness: Witness, key_witness: KeyWitness | None, n_blocks: int,
+                        layout: int = K.LAYOUT_PACKED, as_fr: bool = False):
+        """All advice columns of a FixedAes128Config<K, n_sets> circuit as the prover holds them:
+        [(3*n_sets+1), 2^k] bytes, or [(3*n_sets+1), 2^k, 32] Fr cells with as_fr."""
+        torch = self._torch()
+        ncol = 3 * n_sets + 1
+        shape = (ncol, 1 << k, 32) if as_fr else (ncol, 1 << k)
+        out = torch.empty(shape, dtype=torch.uint8, device=self._dev())
+        ks = KeySlab(*[t.data_ptr() for t in key_witness[:4]]) if key_witness is not None else None
+        rc = self._lib.aesw_assemble_advice_device(
+            self._h, k, n_sets, n_blocks, layout, witness.x.data_ptr(), witness.y.data_ptr(), witness.z.data_ptr(),
+            C.byref(ks) if ks is not None else None, 1 if as_fr else 0, out.data_ptr(), self._stream())
+        self._check(rc, "aesw_assemble_advice_device")
         return out
 
     # -- host entry points (numpy in, numpy out)

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/aesw.h"
 #include "aesw_internal.h"
@@ -19,6 +20,7 @@ struct aesw_ctx {
     uint8_t *d_tables = nullptr;  // 768 B
     uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
     uint8_t *d_rk = nullptr;      // 176 B: round keys of the key given to aesw_schedule_key*
+    int16_t *d_pidx = nullptr;    // dense row -> packed index tables: enc[3][1360], key[3][400]
     bool have_key = false;
     bool xt = false;
     int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
@@ -172,6 +174,16 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), 768), "hipMalloc(tables)");
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_fr_lut), sizeof lut), "hipMalloc(fr_lut)");
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_rk), 256), "hipMalloc(rk)");
+    std::vector<int16_t> pidx(3 * AES_ROWS + 3 * KEY_ROWS);
+    for (int c = 0; c < 3; ++c) {
+        int32_t e[AES_ROWS], kk[KEY_ROWS];
+        aesw_packed_index(c, e);
+        aesw_key_packed_index(c, kk);
+        for (int r = 0; r < AES_ROWS; ++r) pidx[c * AES_ROWS + r] = (int16_t)e[r];
+        for (int r = 0; r < KEY_ROWS; ++r) pidx[3 * AES_ROWS + c * KEY_ROWS + r] = (int16_t)kk[r];
+    }
+    T(hipMalloc(reinterpret_cast<void **>(&ctx->d_pidx), pidx.size() * sizeof(int16_t)), "hipMalloc(pidx)");
+    if (rc == AESW_OK) T(hipMemcpy(ctx->d_pidx, pidx.data(), pidx.size() * sizeof(int16_t), hipMemcpyHostToDevice), "hipMemcpy(pidx)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_fr_lut, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy(fr_lut)");
     if (rc != AESW_OK) {
@@ -194,6 +206,7 @@ void aesw_destroy(aesw_ctx *ctx) {
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
         if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
         if (ctx->d_rk) (void)hipFree(ctx->d_rk);
+        if (ctx->d_pidx) (void)hipFree(ctx->d_pidx);
     }
     delete ctx;
 }
@@ -387,6 +400,31 @@ int aesw_lookup_table_device(aesw_ctx *ctx, uint8_t *d_t0, uint8_t *d_t1, uint8_
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     HIP_TRY(ctx, launch_table(ctx->d_tables, d_t0, d_t1, d_t2, d_t3, reinterpret_cast<hipStream_t>(stream)));
+    return AESW_OK;
+}
+
+int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks, int layout, const uint8_t *d_x,
+                                const uint8_t *d_y, const uint8_t *d_z, const aesw_key_slab *ks, int as_fr, uint8_t *d_out,
+                                void *stream) {
+    if (!ctx || !valid_layout(layout) || k < 2 || k > 32 || n_sets == 0 || n_sets > 1024 || !d_out || !aligned16(d_out))
+        return AESW_ERR_INVALID_ARG;
+    if (n_blocks && (!d_x || !d_y || !d_z)) return AESW_ERR_INVALID_ARG;
+    if (n_blocks > aesw_block_capacity(k, n_sets)) return AESW_ERR_CAPACITY;  // panic in the reference, src/aes128.rs:160-162
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    AssembleParams p{};
+    p.x = d_x; p.y = d_y; p.z = d_z;
+    if (ks) { p.kw = ks->w; p.kx = ks->kx; p.ky = ks->ky; p.kz = ks->kz; }
+    p.pidx = ctx->d_pidx;
+    p.fr_lut = ctx->d_fr_lut;
+    p.out = d_out;
+    p.n_blocks = n_blocks;
+    p.k = k;
+    p.n_sets = n_sets;
+    p.sx = aesw_column_stride(layout, 0); p.sy = aesw_column_stride(layout, 1); p.sz = aesw_column_stride(layout, 2);
+    p.kxs = aesw_key_column_stride(layout, 0); p.kys = aesw_key_column_stride(layout, 1); p.kzs = aesw_key_column_stride(layout, 2);
+    p.packed = layout == AESW_LAYOUT_PACKED;
+    HIP_TRY(ctx, launch_assemble(p, as_fr != 0, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 

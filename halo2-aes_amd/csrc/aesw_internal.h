@@ -35,6 +35,18 @@ hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, 
                           uint32_t max_groups_in_flight, hipStream_t s);
 hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool nt, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
+struct AssembleParams {
+    const uint8_t *x, *y, *z;        // n_blocks slabs
+    const uint8_t *kw, *kx, *ky, *kz;  // one key slab (any may be null)
+    const int16_t *pidx;             // enc[3][1360] then key[3][400]: dense row -> packed index (or -1)
+    const void *fr_lut;              // 256 x 32 B
+    uint8_t *out;
+    uint64_t n_blocks;
+    uint32_t k, n_sets;
+    uint32_t sx, sy, sz, kxs, kys, kzs;  // bytes per block / per key
+    int packed;
+};
+hipError_t launch_assemble(const AssembleParams &p, bool as_fr, hipStream_t s);
 hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, hipStream_t s);
 
 }  // namespace aesw

@@ -428,6 +428,70 @@ __global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restric
 }
 
 // ---------------------------------------------------------------------------
+// full advice columns of a K/N circuit (bytes or Fr cells)
+// ---------------------------------------------------------------------------
+// Cell (column j, row r) -> the slab byte synthesize() puts there (aes_callable
+// placement, src/aes128.rs:303-325), 0 when nothing is ever assigned.
+__device__ __forceinline__ uint32_t advice_cell(const AssembleParams &a, uint32_t col, uint64_t row) {
+    const uint32_t n_adv = 3 * a.n_sets;
+    if (col == n_adv) return (row < WORDS_ROWS && a.kw) ? a.kw[row] : 0u;  // words_column
+    const uint32_t set = col / 3, c = col - 3 * set;
+    const uint64_t rows = (uint64_t)1 << a.k;
+    const uint64_t cap0 = rows >= 1760 ? (rows - 1760) / AES_ROWS : 0, capn = rows / AES_ROWS;
+    if (set == 0 && row < KEY_ROWS) {
+        const uint8_t *kc = c == 0 ? a.kx : c == 1 ? a.ky : a.kz;
+        if (!kc) return 0u;
+        const int idx = a.packed ? a.pidx[3 * AES_ROWS + c * KEY_ROWS + row] : (int)row;
+        return idx >= 0 ? kc[idx] : 0u;
+    }
+    const uint64_t base = set == 0 ? KEY_ROWS : 0;
+    if (row < base) return 0u;
+    const uint64_t rr = row - base;
+    const uint64_t bi = rr / AES_ROWS;
+    const uint32_t r = (uint32_t)(rr - bi * AES_ROWS);
+    if (bi >= (set == 0 ? cap0 : capn)) return 0u;
+    const uint64_t b = (set == 0 ? 0 : cap0 + (uint64_t)(set - 1) * capn) + bi;
+    if (b >= a.n_blocks) return 0u;
+    const uint8_t *sc = c == 0 ? a.x : c == 1 ? a.y : a.z;
+    const uint32_t stride = c == 0 ? a.sx : c == 1 ? a.sy : a.sz;
+    const int idx = a.packed ? a.pidx[c * AES_ROWS + r] : (int)r;
+    return idx >= 0 ? sc[b * stride + idx] : 0u;
+}
+
+template <bool AS_FR>
+__global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
+    __shared__ u32x4 lut[AS_FR ? 512 : 1];
+    if (AS_FR) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) lut[i] = reinterpret_cast<const u32x4 *>(a.fr_lut)[i];
+        __syncthreads();
+    }
+    const uint64_t rows = (uint64_t)1 << a.k;
+    const uint64_t cells = (uint64_t)(3 * a.n_sets + 1) * rows;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if (AS_FR) {
+        // one lane = one 16-byte half cell: a wave writes 1 KiB contiguously
+        u32x4 *out = reinterpret_cast<u32x4 *>(a.out);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells * 2; i += stride) {
+            const uint64_t cell = i >> 1;
+            const uint32_t v = advice_cell(a, (uint32_t)(cell >> a.k), cell & (rows - 1));
+            __builtin_nontemporal_store(lut[v * 2 + (uint32_t)(i & 1)], &out[i]);
+        }
+    } else {
+        // one lane = four consecutive cells of one column (rows is a multiple of 4)
+        uint32_t *out = reinterpret_cast<uint32_t *>(a.out);
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells / 4; i += stride) {
+            const uint64_t cell = i * 4;
+            const uint32_t col = (uint32_t)(cell >> a.k);
+            const uint64_t row = cell & (rows - 1);
+            uint32_t v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v |= advice_cell(a, col, row + j) << (8 * j);
+            out[i] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 template <int L, bool XT, int KM, bool KEMIT, bool NT>
@@ -500,6 +564,16 @@ hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool n
 
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s) {
     hipLaunchKernelGGL(table_kernel, dim3((66561 + 255) / 256), dim3(256), 0, s, tables, t0, t1, t2, t3);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const AssembleParams &p, bool as_fr, hipStream_t s) {
+    const uint64_t cells = (uint64_t)(3 * p.n_sets + 1) << p.k;
+    uint64_t blocks = ((as_fr ? cells * 2 : cells / 4) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) blocks = 1;
+    if (as_fr) hipLaunchKernelGGL(assemble_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(assemble_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

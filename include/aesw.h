@@ -148,6 +148,21 @@ int aesw_lookup_table_device(aesw_ctx *ctx, uint8_t *d_t0, uint8_t *d_t1, uint8_
 int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cells, uint8_t *d_fr,
                           void *stream);
 
+/* The advice columns of a FixedAes128Config<K, n_sets> circuit exactly as the
+ * prover holds them after synthesize(): 3*n_sets+1 columns of 2^k cells (set i
+ * -> columns 3i, 3i+1, 3i+2; words_column last, src/aes128.rs:54-60,
+ * src/key_schedule.rs:48), the key rows and block b placed where
+ * aesw_block_placement() says, never-assigned cells 0.  Inputs: n_blocks slabs
+ * (d_x, d_y, d_z in `layout`) and one key slab (optional).  as_fr = 0: one byte
+ * per cell; as_fr = 1: 32-byte little-endian Montgomery bn256::Fr per cell, so
+ * the host can bulk-copy a column into halo2's advice polynomial.
+ * d_out holds (3*n_sets+1) << k cells, column after column.
+ * AESW_ERR_CAPACITY when n_blocks does not fit (the reference panics). */
+int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks,
+                                int layout, const uint8_t *d_x, const uint8_t *d_y,
+                                const uint8_t *d_z, const aesw_key_slab *d_key_slab, int as_fr,
+                                uint8_t *d_out, void *stream);
+
 /* ---- host-pointer entry points (synchronous) ----------------------------- */
 /* Same contracts with host buffers.  Blocks are cut into chunks ("chunk_blocks"
  * option); chunk i's kernel runs while chunk i-1's columns travel D2H on a

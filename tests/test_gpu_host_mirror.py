@@ -96,3 +96,33 @@ def test_keys_should_be_scheduled(ctx, pkg):
     with pytest.raises(pkg.AeswError) as e:
         pkg.HostCircuit.aes(ctx, 13, 1, np.zeros(16, np.uint8), np.zeros((1, 16), np.uint8), skip_schedule_key=True)
     assert e.value.status == 6 and "Keys should be scheduled" in str(e.value)
+
+
+@pytest.mark.parametrize("layout_name", ["dense", "packed"])
+def test_assembled_advice_columns_equal_synthesize(ctx, pkg, oracle, layout_name):
+    """aesw_assemble_advice_device: the full advice columns (bytes, and 32-byte Fr cells) of a K=15, N=3
+    circuit straight from the device == what the restated synthesize() assigns, zeros elsewhere."""
+    import torch
+    layout = pkg.LAYOUT_DENSE if layout_name == "dense" else pkg.LAYOUT_PACKED
+    rng = np.random.default_rng(77)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    k, n_sets = 15, 3
+    n = pkg.block_capacity(k, n_sets) - 1            # 22 + 24 + 24 - 1: the last set stays partly empty
+    pts = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    kw = ctx.schedule_key(torch.from_numpy(key).cuda(), layout=layout)
+    w = ctx.encrypt_witness(torch.from_numpy(pts).cuda(), None, layout=layout)
+    cols = ctx.assemble_advice(k, n_sets, w, kw, n, layout=layout)
+    fr = ctx.assemble_advice(k, n_sets, w, kw, n, layout=layout, as_fr=True)
+    torch.cuda.synchronize()
+    cols, fr = cols.cpu().numpy(), fr.cpu().numpy()
+    r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    lut = np.stack([np.frombuffer(((v << 256) % r).to_bytes(32, "little"), np.uint8) for v in range(256)])
+    with oracle.circuit(k, n_sets, key, pts, record_copies=False) as o:
+        assert o.status == 0
+        for c in range(3 * n_sets + 1):
+            exp = o.advice(c)
+            assert np.array_equal(cols[c], exp), "advice column %d" % c
+            assert np.array_equal(fr[c], lut[exp]), "Fr cells of advice column %d" % c
+    with pytest.raises(pkg.AeswError) as e:
+        ctx.assemble_advice(k, n_sets, w, kw, n + 2, layout=layout)
+    assert e.value.status == 5
