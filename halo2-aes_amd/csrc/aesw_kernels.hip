@@ -494,6 +494,22 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+// Dynamic LDS above 48 KiB needs the attribute once per (kernel, device); remember
+// it so that the launch path stays free of extra runtime calls.
+static hipError_t allow_large_lds(const void *fn, size_t lds) {
+    if (lds <= 48 * 1024) return hipSuccess;
+    struct Seen { const void *fn; int dev; size_t lds; };
+    static Seen seen[256];
+    static int n_seen = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].fn == fn && seen[i].dev == dev && seen[i].lds >= lds) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && n_seen < 256) seen[n_seen++] = Seen{fn, dev, lds};
+    return e;
+}
+
 template <int L, bool XT, int KM, bool KEMIT, bool NT>
 static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, hipStream_t stream) {
     const int bpg = waves * BPW;
@@ -505,8 +521,8 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, hipSt
     const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
     const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KM == KM_PBK, KEMIT);
     auto k = encrypt_kernel<L, XT, KM, KEMIT, NT>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k), lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3(grid), dim3(waves * LANES), lds, stream, p);
@@ -544,8 +560,8 @@ static hipError_t launch_key_t(const KeyParams &p, int waves, hipStream_t stream
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = TAB_BYTES + (size_t)waves * (Stage<L>::KEY_BYTES + Stage<L>::RK_BYTES_W);
     auto k = key_kernel<L, XT, NT>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k), lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k, dim3((unsigned)groups), dim3(waves * LANES), lds, stream, p);

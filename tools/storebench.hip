@@ -153,7 +153,8 @@ __global__ void k_stream(u32x4* out, size_t n16) {
 }
 
 int main(int argc, char** argv) {
-    const uint64_t nblk = 1ull << 20;
+    const uint64_t nblk = 1ull << (argc > 1 ? atoi(argv[1]) : 20);
+    const bool quick = argc > 2;
     uint8_t *x, *y, *z;
     CK(hipMalloc(&x, nblk * XS + 4096)); CK(hipMalloc(&y, nblk * YS + 4096)); CK(hipMalloc(&z, nblk * ZS + 4096));
     const double bytes = (double)nblk * (XS + YS + ZS);
@@ -162,7 +163,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 2; ++i) launch();
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        const int reps = 10;
+        const int reps = 40;
         for (int i = 0; i < reps; ++i) launch();
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -179,6 +180,7 @@ int main(int argc, char** argv) {
         }
     }
     for (int spin : {0, 200}) {
+        if (quick) break;
         for (int waves : {1, 4}) {
             for (int ldskb : {0, 8, 16, 32}) {
                 char name[128];
@@ -191,6 +193,7 @@ int main(int argc, char** argv) {
         }
     }
     for (int S : {1, 2, 3, 5, 9}) {
+        if (quick) break;
         for (int waves : {1, 4}) {
             char name[128];
             const unsigned grid = (unsigned)((nblk + 16 * waves - 1) / (16 * waves));
