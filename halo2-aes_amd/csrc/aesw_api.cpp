@@ -27,6 +27,7 @@ struct aesw_ctx {
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
     bool nt = false;
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
+    bool xcd_remap = false;
     int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
     std::string last_error;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
@@ -300,6 +301,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "waves_pbk")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_pbk = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "nt_stores")) { ctx->nt = value != 0; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
+    if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
     if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { if (value < 64) return AESW_ERR_INVALID_ARG; ctx->chunk_blocks = value; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
@@ -311,6 +313,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "waves_pbk")) { *value = ctx->waves_pbk; return AESW_OK; }
     if (!std::strcmp(name, "nt_stores")) { *value = ctx->nt; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { *value = ctx->grid_cap; return AESW_OK; }
+    if (!std::strcmp(name, "xcd_remap")) { *value = ctx->xcd_remap; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { *value = ctx->chunk_blocks; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
 }
@@ -374,9 +377,9 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
     }
     const int km = per_block_keys ? 0 : (d_keys ? 1 : 2);
     EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, d_x, d_y, d_z, d_ct,
-                per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n, 0};
+                per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n, 0, 0};
     HIP_TRY(ctx, launch_encrypt(p, layout, ctx->xt, km, per_block_keys && kemit, auto_waves(ctx, layout, per_block_keys != 0),
-                                ctx->nt, (uint32_t)ctx->grid_cap, s));
+                                ctx->nt, (uint32_t)ctx->grid_cap, ctx->xcd_remap, s));
     return AESW_OK;
 }
 

@@ -238,7 +238,14 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     const uint32_t stage0 = TAB_BYTES + RKS_BYTES + wave * WAVE_LDS;  // this wave's slab
 
     // the first group's inputs first, so their latency hides behind the table load
-    auto group_blk0 = [&](uint32_t grp) { return ((uint64_t)grp * waves + wave) * BPW; };
+    // Optional XCD-aware order (workgroups are dealt round-robin over the 8 XCDs): ids that share an
+    // XCD walk one contiguous eighth of the block groups.  Bijective for any ngroups (speed only).
+    auto remap = [&](uint32_t id) -> uint32_t {
+        if (!a.xcd_remap) return id;
+        const uint32_t q = a.ngroups / 8, r = a.ngroups % 8, xcd = id % 8;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
+    };
+    auto group_blk0 = [&](uint32_t grp) { return ((uint64_t)remap(grp) * waves + wave) * BPW; };
     auto group_nvalid = [&](uint64_t b0) {
         const int64_t left = (int64_t)a.n - (int64_t)b0;
         return left >= BPW ? BPW : (left > 0 ? (int)left : 0);
@@ -511,13 +518,14 @@ static hipError_t allow_large_lds(const void *fn, size_t lds) {
 }
 
 template <int L, bool XT, int KM, bool KEMIT, bool NT>
-static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, hipStream_t stream) {
+static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool xr, hipStream_t stream) {
     const int bpg = waves * BPW;
     const uint64_t groups = (p0.n + bpg - 1) / bpg;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
     EncParams p = p0;
     p.ngroups = (uint32_t)groups;
+    p.xcd_remap = xr ? 1u : 0u;
     const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
     const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KM == KM_PBK, KEMIT);
     auto k = encrypt_kernel<L, XT, KM, KEMIT, NT>;
@@ -530,26 +538,27 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, hipSt
 }
 
 template <int L, bool XT, int KM, bool KEMIT>
-static hipError_t launch_enc_nt(const EncParams &p, int waves, bool nt, uint32_t cap, hipStream_t s) {
-    return nt ? launch_enc<L, XT, KM, KEMIT, true>(p, waves, cap, s) : launch_enc<L, XT, KM, KEMIT, false>(p, waves, cap, s);
+static hipError_t launch_enc_nt(const EncParams &p, int waves, bool nt, uint32_t cap, bool xr, hipStream_t s) {
+    return nt ? launch_enc<L, XT, KM, KEMIT, true>(p, waves, cap, xr, s) : launch_enc<L, XT, KM, KEMIT, false>(p, waves, cap, xr, s);
 }
 
 template <int L, bool XT>
-static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, bool nt, uint32_t cap, hipStream_t s) {
-    if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, cap, s);
-    if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, cap, s);
-    return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, cap, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, cap, s);
+static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, bool nt, uint32_t cap, bool xr, hipStream_t s) {
+    if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, cap, xr, s);
+    if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, cap, xr, s);
+    return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, cap, xr, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, cap, xr, s);
 }
 
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, bool nt,
-                          uint32_t max_groups_in_flight, hipStream_t s) {
+                          uint32_t max_groups_in_flight, bool xcd_remap, hipStream_t s) {
     if (waves < 1 || waves > 4 || keymode < 0 || keymode > 2) return hipErrorInvalidValue;
     const uint32_t cap = max_groups_in_flight;
+    const bool xr = xcd_remap && cap == 0;  // the remap assumes one workgroup per group
     if (layout == DENSE)
-        return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, s)
-                  : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, s);
-    return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, cap, s)
-              : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, cap, s);
+        return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, xr, s)
+                  : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, xr, s);
+    return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, cap, xr, s)
+              : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, cap, xr, s);
 }
 
 template <int L, bool XT, bool NT>

@@ -182,7 +182,9 @@ int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint
 
 /* ---- tuning / introspection (bench.py, tests) ----------------------------- */
 /* name: "waves_shared" / "waves_pbk" (waves per group, 0 = auto, 1..4),
- * "nt_stores" (0/1), "force_table_path" (1), "chunk_blocks".  Unknown -> INVALID_ARG */
+ * "nt_stores" (0/1), "grid_cap" (max workgroups per launch, 0 = one per block
+ * group), "xcd_remap" (0/1), "force_table_path" (1), "chunk_blocks".
+ * Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);
 /* 1 when mul2/mul3 passed to aesw_create() equal GF(2^8) xtime tables, so the

@@ -220,6 +220,24 @@ def test_schedule_key_then_encrypt(pkg, oracle, layout):
     c.close()
 
 
+def test_xcd_remap(pkg, oracle):
+    """xcd_remap only permutes which workgroup takes which block group (any group count, incl. non-multiples of 8)."""
+    import torch
+    c = pkg.Context(0)
+    c.set_option("xcd_remap", 1)
+    for n in (64 * 11 + 5, 64 * 8, 37):
+        pt, keys = _inputs(n)
+        for k_host in (keys[0], keys):
+            got = c.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(np.ascontiguousarray(k_host)).cuda(),
+                                    layout=ol.PACKED, want_ct=True)
+            torch.cuda.synchronize()
+            exp = oracle.encrypt_witness(pt, k_host, layout=ol.PACKED)
+            for col in "xyz":
+                _cmp(col, getattr(got, col), getattr(exp, col))
+            _cmp("ct", got.ct, exp.ct)
+    c.close()
+
+
 @pytest.mark.parametrize("cap", [1, 3, 512])
 def test_group_striding(pkg, oracle, cap):
     """grid_cap < number of block groups: every workgroup walks several groups, reusing its LDS windows."""
