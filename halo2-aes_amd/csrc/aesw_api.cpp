@@ -25,7 +25,7 @@ struct aesw_ctx {
     bool xt = false;
     int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
-    bool nt = false;
+    int nt = 2;  // store flavour: 0 plain, 1 nontemporal, 2 write-through (sc1, default: nothing left dirty in L2 at kernel end)
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
     bool xcd_remap = false;
     int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
@@ -299,7 +299,8 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return AESW_ERR_INVALID_ARG;
     if (!std::strcmp(name, "waves_shared")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_shared = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "waves_pbk")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_pbk = (int)value; return AESW_OK; }
-    if (!std::strcmp(name, "nt_stores")) { ctx->nt = value != 0; return AESW_OK; }
+    if (!std::strcmp(name, "nt_stores")) { ctx->nt = value != 0 ? 1 : 0; return AESW_OK; }
+    if (!std::strcmp(name, "store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->nt = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
     if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }
@@ -311,7 +312,8 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!ctx || !name || !value) return AESW_ERR_INVALID_ARG;
     if (!std::strcmp(name, "waves_shared")) { *value = ctx->waves_shared; return AESW_OK; }
     if (!std::strcmp(name, "waves_pbk")) { *value = ctx->waves_pbk; return AESW_OK; }
-    if (!std::strcmp(name, "nt_stores")) { *value = ctx->nt; return AESW_OK; }
+    if (!std::strcmp(name, "nt_stores")) { *value = ctx->nt == 1; return AESW_OK; }
+    if (!std::strcmp(name, "store_mode")) { *value = ctx->nt; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { *value = ctx->grid_cap; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { *value = ctx->xcd_remap; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { *value = ctx->chunk_blocks; return AESW_OK; }
@@ -325,7 +327,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
 static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
     if (pbk) return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_PACKED ? 2 : 1);
     if (ctx->waves_shared) return ctx->waves_shared;
-    return layout == AESW_LAYOUT_PACKED ? 4 : 2;
+    return 4;  // 64 blocks per group: line-aligned in every column, fewest table loads
 }
 
 int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, const aesw_key_slab *ks, void *stream) {

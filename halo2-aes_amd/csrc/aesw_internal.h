@@ -32,9 +32,9 @@ struct KeyParams {
 };
 
 // key mode: 0 = per-block keys, 1 = shared key expanded in the kernel, 2 = shared key scheduled earlier (p.rk)
-hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, bool nt,
+hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, int store_mode,
                           uint32_t max_groups_in_flight, bool xcd_remap, hipStream_t s);
-hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool nt, hipStream_t s);
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
 struct AssembleParams {
     const uint8_t *x, *y, *z;        // n_blocks slabs

@@ -97,9 +97,21 @@ template <> struct PieceT<16> { using type = u32x4; };
 template <> struct PieceT<8> { using type = u32x2; };
 template <> struct PieceT<4> { using type = uint32_t; };
 
-template <bool NT, class V>
-__device__ __forceinline__ void gstore(V *p, const V &v) {
-    if (NT) __builtin_nontemporal_store(v, p);
+// Store flavours: 0 plain, 1 nontemporal (nt), 2 write-through at agent scope
+// (sc1).  Plain / nt lines stay dirty in the XCD's L2 and are written back at
+// the kernel boundary (that costs dirty bytes / ~6 TB/s after the last wave has
+// finished); sc1 stores leave L2 as they are issued, so a launch ends with
+// nothing left to flush (MI355X_MICROARCH.md, "stores of each flavour").
+template <int MODE>
+__device__ __forceinline__ void gstore(u32x4 *p, const u32x4 &v) {
+    if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    else if (MODE == 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <int MODE>
+__device__ __forceinline__ void gstore(u32x2 *p, const u32x2 &v) {
+    if (MODE == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    else if (MODE == 1) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 
@@ -107,7 +119,7 @@ __device__ __forceinline__ void gstore(V *p, const V &v) {
 // lane>>3 (+8 in the second pass), 16-byte piece lane&7): 8 whole lines per
 // store instruction.  R must be a compile-time constant at the call site (the
 // round loop is fully unrolled) so every window offset folds to an immediate.
-template <class W, bool NT>
+template <class W, int NT>
 __device__ __forceinline__ void flush_lines(const int R, const uint8_t *lds, uint32_t stage, uint8_t *g, int nvalid,
                                             int lane) {
     const int sub = lane & 7;
@@ -126,7 +138,7 @@ __device__ __forceinline__ void flush_lines(const int R, const uint8_t *lds, uin
 }
 
 // Fully contiguous: nvalid*STRIDE bytes from LDS stage to g.
-template <int PIECE, int STRIDE, bool NT>
+template <int PIECE, int STRIDE, int NT>
 __device__ __forceinline__ void flush_contig(const uint8_t *lds, uint32_t stage, uint8_t *g, int nvalid, int lane) {
     using V = typename PieceT<PIECE>::type;
     static_assert(STRIDE % PIECE == 0, "piece alignment");
@@ -199,7 +211,7 @@ __device__ __forceinline__ void key_phase(uint8_t *lds, uint32_t stage, uint32_t
     }
 }
 
-template <int L, bool NT>
+template <int L, int NT>
 __device__ __forceinline__ void key_flush(const uint8_t *lds, uint32_t stage, const KeyOut &o, uint64_t blk0,
                                           int nvalid, int lane) {
     using G = Geo<L>;
@@ -220,7 +232,7 @@ __device__ __forceinline__ void key_flush(const uint8_t *lds, uint32_t stage, co
 //         the 44 round-key words come from global memory, no barrier for them.
 enum : int { KM_PBK = 0, KM_SHARED = 1, KM_PRE = 2 };
 
-template <int L, bool XT, int KM, bool KEMIT, bool NT>
+template <int L, bool XT, int KM, bool KEMIT, int NT>
 __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     constexpr bool PBK = KM == KM_PBK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -360,7 +372,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
 // ---------------------------------------------------------------------------
 // key-schedule witness kernel (src/key_schedule.rs:80-224 for n keys)
 // ---------------------------------------------------------------------------
-template <int L, bool XT, bool NT>
+template <int L, bool XT, int NT>
 __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using St = Stage<L>;
@@ -517,7 +529,7 @@ static hipError_t allow_large_lds(const void *fn, size_t lds) {
     return e;
 }
 
-template <int L, bool XT, int KM, bool KEMIT, bool NT>
+template <int L, bool XT, int KM, bool KEMIT, int NT>
 static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool xr, hipStream_t stream) {
     const int bpg = waves * BPW;
     const uint64_t groups = (p0.n + bpg - 1) / bpg;
@@ -538,18 +550,20 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
 }
 
 template <int L, bool XT, int KM, bool KEMIT>
-static hipError_t launch_enc_nt(const EncParams &p, int waves, bool nt, uint32_t cap, bool xr, hipStream_t s) {
-    return nt ? launch_enc<L, XT, KM, KEMIT, true>(p, waves, cap, xr, s) : launch_enc<L, XT, KM, KEMIT, false>(p, waves, cap, xr, s);
+static hipError_t launch_enc_nt(const EncParams &p, int waves, int nt, uint32_t cap, bool xr, hipStream_t s) {
+    return nt == 2 ? launch_enc<L, XT, KM, KEMIT, 2>(p, waves, cap, xr, s)
+         : nt == 1 ? launch_enc<L, XT, KM, KEMIT, 1>(p, waves, cap, xr, s)
+                   : launch_enc<L, XT, KM, KEMIT, 0>(p, waves, cap, xr, s);
 }
 
 template <int L, bool XT>
-static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, bool nt, uint32_t cap, bool xr, hipStream_t s) {
+static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, int nt, uint32_t cap, bool xr, hipStream_t s) {
     if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, cap, xr, s);
     if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, cap, xr, s);
     return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, cap, xr, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, cap, xr, s);
 }
 
-hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, bool nt,
+hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, int nt,
                           uint32_t max_groups_in_flight, bool xcd_remap, hipStream_t s) {
     if (waves < 1 || waves > 4 || keymode < 0 || keymode > 2) return hipErrorInvalidValue;
     const uint32_t cap = max_groups_in_flight;
@@ -561,7 +575,7 @@ hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, 
               : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, cap, xr, s);
 }
 
-template <int L, bool XT, bool NT>
+template <int L, bool XT, int NT>
 static hipError_t launch_key_t(const KeyParams &p, int waves, hipStream_t stream) {
     const int bpg = waves * BPW;
     const uint64_t groups = (p.n + bpg - 1) / bpg;
@@ -577,14 +591,15 @@ static hipError_t launch_key_t(const KeyParams &p, int waves, hipStream_t stream
     return hipGetLastError();
 }
 
-hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, bool nt, hipStream_t s) {
+template <int L, bool XT>
+static hipError_t launch_key_nt(const KeyParams &p, int waves, int nt, hipStream_t s) {
+    return nt == 2 ? launch_key_t<L, XT, 2>(p, waves, s) : nt == 1 ? launch_key_t<L, XT, 1>(p, waves, s) : launch_key_t<L, XT, 0>(p, waves, s);
+}
+
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int nt, hipStream_t s) {
     if (waves < 1 || waves > 4) return hipErrorInvalidValue;
-    if (layout == DENSE) {
-        if (xt) return nt ? launch_key_t<DENSE, true, true>(p, waves, s) : launch_key_t<DENSE, true, false>(p, waves, s);
-        return nt ? launch_key_t<DENSE, false, true>(p, waves, s) : launch_key_t<DENSE, false, false>(p, waves, s);
-    }
-    if (xt) return nt ? launch_key_t<PACKED, true, true>(p, waves, s) : launch_key_t<PACKED, true, false>(p, waves, s);
-    return nt ? launch_key_t<PACKED, false, true>(p, waves, s) : launch_key_t<PACKED, false, false>(p, waves, s);
+    if (layout == DENSE) return xt ? launch_key_nt<DENSE, true>(p, waves, nt, s) : launch_key_nt<DENSE, false>(p, waves, nt, s);
+    return xt ? launch_key_nt<PACKED, true>(p, waves, nt, s) : launch_key_nt<PACKED, false>(p, waves, nt, s);
 }
 
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s) {

@@ -182,7 +182,7 @@ int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint
 
 /* ---- tuning / introspection (bench.py, tests) ----------------------------- */
 /* name: "waves_shared" / "waves_pbk" (waves per group, 0 = auto, 1..4),
- * "nt_stores" (0/1), "grid_cap" (max workgroups per launch, 0 = one per block
+ * "store_mode" (0 plain, 1 nontemporal, 2 write-through sc1), "nt_stores" (0/1), "grid_cap" (max workgroups per launch, 0 = one per block
  * group), "xcd_remap" (0/1), "force_table_path" (1), "chunk_blocks".
  * Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);

@@ -168,13 +168,13 @@ def test_generic_table_path(ctx, pkg, oracle, layout):
 
 
 @pytest.mark.parametrize("waves", [1, 2, 3, 4])
-@pytest.mark.parametrize("nt", [0, 1])
+@pytest.mark.parametrize("nt", [0, 1, 2])
 def test_launch_options(pkg, oracle, waves, nt):
     import torch
     c = pkg.Context(0)
     c.set_option("waves_shared", waves)
     c.set_option("waves_pbk", waves)
-    c.set_option("nt_stores", nt)
+    c.set_option("store_mode", nt)
     pt, keys = _inputs(300)
     for layout in (ol.DENSE, ol.PACKED):
         for k_host in (keys[0], keys):
