@@ -104,13 +104,15 @@ template <> struct PieceT<4> { using type = uint32_t; };
 // nothing left to flush (MI355X_MICROARCH.md, "stores of each flavour").
 template <int MODE>
 __device__ __forceinline__ void gstore(u32x4 *p, const u32x4 &v) {
-    if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    // hipcc neither counts nor pads an asm store: the trailing s_nop 1 covers the ">64-bit store data
+    // overwritten by the next instruction" hazard (cdna guide 5.7 item 1); nothing ever waits on these stores.
+    if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
     else if (MODE == 1) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 template <int MODE>
 __device__ __forceinline__ void gstore(u32x2 *p, const u32x2 &v) {
-    if (MODE == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    if (MODE == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
     else if (MODE == 1) __builtin_nontemporal_store(v, p);
     else *p = v;
 }

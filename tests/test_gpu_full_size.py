@@ -27,8 +27,8 @@ def _check_slab_relations(torch, pkg, x, y, z, pt, rk, sbox, mul2, mul3):
 
     def eq(a, b, what):
         if not torch.equal(a, b):
-            bad = (a != b).nonzero()[0].tolist()
-            raise AssertionError("%s violated at block %d, offset %d" % (what, bad[0], bad[1]))
+            bad = (a != b).nonzero()
+            raise AssertionError("%s violated in %d places, first at %s" % (what, bad.shape[0], bad[0].tolist()))
 
     eq(x[:, 0:16], pt, "rows 0-15 x == plaintext")
     eq(x[:, 16:32], pt, "rows 16-31 x == plaintext (copy)")
