@@ -186,3 +186,40 @@ def test_config4_2p24_blocks_one_gpu(ctx, pkg, oracle):
     for r in range(8):
         lo, hi = pkg.sharding.shard_range(n, r, 8)
         assert (lo, hi) == (r << 21, (r + 1) << 21)
+
+
+@pytest.mark.parametrize("layout_name", ["packed", "dense"])
+@pytest.mark.parametrize("keymode", ["scheduled", "shared", "per_block"])
+def test_stress_byte_exact_2p18(ctx, pkg, oracle, layout_name, keymode):
+    """Timing-dependent faults (store-data hazards, LDS ordering between a wave's flush and its next
+    round) only show at scale: 2^18 + 37 blocks, every byte against the oracle, every key mode and layout."""
+    import torch
+    layout = pkg.LAYOUT_PACKED if layout_name == "packed" else pkg.LAYOUT_DENSE
+    n = (1 << 18) + 37
+    rng = np.random.default_rng(1000 + 10 * ["packed", "dense"].index(layout_name) + ["scheduled", "shared", "per_block"].index(keymode))
+    pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    keys = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    dpt = torch.from_numpy(pt).cuda()
+    if keymode == "scheduled":
+        ctx.schedule_key(torch.from_numpy(keys[0]).cuda(), layout=layout, key_slab=False)
+        got = ctx.encrypt_witness(dpt, None, layout=layout, want_ct=True)
+        k_host = keys[0]
+    elif keymode == "shared":
+        got = ctx.encrypt_witness(dpt, torch.from_numpy(keys[0]).cuda(), layout=layout, want_ct=True)
+        k_host = keys[0]
+    else:
+        got = ctx.encrypt_witness(dpt, torch.from_numpy(keys).cuda(), layout=layout, want_ct=True, key_slab=True)
+        k_host = keys
+    torch.cuda.synchronize()
+    threads = min(64, os.cpu_count() or 8)
+    exp = oracle.encrypt_witness(pt, k_host, layout=layout, threads=threads)
+    for c in "xyz":
+        a, e = getattr(got, c).cpu().numpy(), getattr(exp, c)
+        if not np.array_equal(a, e):
+            bad = np.nonzero(a != e)[0]
+            raise AssertionError("column %s: %d bytes differ, first at %d" % (c, bad.size, bad[0]))
+    assert np.array_equal(got.ct.cpu().numpy(), exp.ct)
+    if keymode == "per_block":
+        kexp = oracle.key_schedule_witness(keys, layout=layout, threads=threads)
+        for c in ("w", "kx", "ky", "kz"):
+            assert np.array_equal(getattr(got.key, c).cpu().numpy(), getattr(kexp, c)), c
