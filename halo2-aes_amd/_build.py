@@ -47,8 +47,18 @@ def build_product(force: bool = False) -> Path:
                    ROOT / "include" / "aesw_host.h", host / "halo2_lite.hpp", host / "aes_gadget.hpp"]
     if not force and _newer(LIB, deps):
         return LIB
-    tmp = LIB.with_suffix(".so.tmp")
-    _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-          "-o", str(tmp)] + [str(s) for s in srcs])
-    os.replace(tmp, LIB)
+    # several ranks may get here at once (torchrun): serialise on a lock file, build under a
+    # private name, publish with an atomic rename
+    import fcntl
+    with open(PKG / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _newer(LIB, deps):
+                return LIB  # another process built it while we waited
+            tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
+            _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+                  "-o", str(tmp)] + [str(s) for s in srcs])
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
