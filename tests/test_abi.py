@@ -105,6 +105,32 @@ def test_selector_tags_match_oracle_circuit(pkg, oracle):
         assert np.array_equal(c.fixed()[:96], rc)
 
 
+def test_block_placement_sweep(pkg):
+    """aes_callable() as a pure function, against a direct restatement of src/aes128.rs:303-325."""
+    def reference_walk(k, n_sets, count_blocks):
+        current, count, out = 0, 0, []
+        for _ in range(count_blocks):
+            max_row = 2 ** k - (1760 if current == 0 else 0)
+            if max_row >= count * 1360 + 1360:
+                pass
+            elif current < n_sets - 1:
+                current, count = current + 1, 0
+            else:
+                return out, True   # panic
+            out.append((current, (400 if current == 0 else 0) + count * 1360))
+            count += 1
+        return out, False
+    for k, n_sets in ((11, 1), (11, 3), (12, 2), (13, 5), (16, 4), (20, 5)):
+        cap = pkg.block_capacity(k, n_sets)
+        walk, panicked = reference_walk(k, n_sets, cap + 1)
+        assert panicked and len(walk) == cap
+        step = max(1, cap // 200)
+        for b in list(range(0, cap, step)) + [cap - 1] if cap else []:
+            assert pkg.block_placement(k, n_sets, b) == walk[b]
+        with pytest.raises(pkg.AeswError):
+            pkg.block_placement(k, n_sets, cap)
+
+
 def test_no_cpu_path(pkg):
     """Without a gfx950 device the library refuses to create a context."""
     import torch
