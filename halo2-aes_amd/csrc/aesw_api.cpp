@@ -581,6 +581,14 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         if (ks->kz) HIP_TRY(ctx, hipMemcpy(ks->kz, kz1.p, kzs, hipMemcpyDeviceToHost));
     }
 
+    // Whatever happens below, no copy may still be writing the caller's buffers when we return.
+    struct SyncGuard {
+        aesw_ctx *c;
+        ~SyncGuard() {
+            (void)hipStreamSynchronize(c->s_copy);
+            (void)hipStreamSynchronize(c->s_compute);
+        }
+    } sync_guard{ctx};
     hipEvent_t done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
     struct EvGuard {
         hipEvent_t *a, *b;

@@ -44,23 +44,24 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
         raise ValueError("counts/strides do not match world size / columns")
     total = sum(counts)
     offs = [sum(counts[:r]) for r in range(world)]
+    # One grouped batch of point-to-point operations: with the nccl backend (RCCL) the group is
+    # issued as a single ncclGroupStart/End, so the root's receives from all peers proceed
+    # concurrently, each over its own xGMI link, instead of one peer after the other.
+    ops = []
+    outs = None
     if rank == dst:
         outs = [torch.empty(total * s, dtype=torch.uint8, device=c.device) for c, s in zip(columns, strides)]
-        reqs = []
         for c, (col, s) in enumerate(zip(columns, strides)):
             for r in range(world):
                 view = outs[c][offs[r] * s:(offs[r] + counts[r]) * s]
                 if r == dst:
                     view.copy_(col[:counts[r] * s])
                 elif counts[r]:
-                    reqs.append(dist.irecv(view, src=r, group=group))
-        for q in reqs:
+                    ops.append(dist.P2POp(dist.irecv, view, r, group))
+    elif counts[rank]:
+        for col, s in zip(columns, strides):
+            ops.append(dist.P2POp(dist.isend, col[:counts[rank] * s].contiguous(), dst, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return outs
-    reqs = []
-    for col, s in zip(columns, strides):
-        if counts[rank]:
-            reqs.append(dist.isend(col[:counts[rank] * s].contiguous(), dst=dst, group=group))
-    for q in reqs:
-        q.wait()
-    return None
+    return outs
