@@ -39,14 +39,40 @@ struct HostKSink {
 
 uint32_t ld32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 
+// One column's flush after round R for the whole wave, with the kernel's incremental FlushState
+// (states[lane] carried from round to round).
 template <class W>
-void flush_col(int R, const std::vector<uint8_t> &stage, uint8_t *g, int nvalid) {
+void flush_col(int R, const std::vector<uint8_t> &stage, uint8_t *g, std::vector<FlushState<W>> &states) {
     for (int lane = 0; lane < 64; ++lane)
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+            const int lo = states[lane].advance(R, h);
             for (int t = 0; t < flush_maxc<W>(R); ++t) {
-                const FlushPiece fp = flush_piece<W>(R, (lane >> 3) + 8 * h, lane & 7, t, nvalid);
+                const FlushPiece fp = states[lane].piece(R, h, lo, lane & 7, t);
                 if (fp.ok) std::memcpy(g + fp.P, stage.data() + fp.lds_off, 16);
             }
+        }
+}
+
+// FlushState (incremental) against flush_piece (closed form) for every round, lane, piece and
+// number of valid blocks: returns the number of disagreements on stored pieces.
+template <class W>
+int flush_forms_disagree() {
+    int bad = 0;
+    for (int nvalid = 1; nvalid <= BPW; ++nvalid)
+        for (int lane = 0; lane < 64; ++lane) {
+            FlushState<W> st;
+            st.init(lane, nvalid);
+            for (int R = 1; R <= 9; ++R)
+                for (int h = 0; h < 2; ++h) {
+                    const int lo = st.advance(R, h);
+                    for (int t = 0; t < flush_maxc<W>(R); ++t) {
+                        const FlushPiece a = st.piece(R, h, lo, lane & 7, t);
+                        const FlushPiece b = flush_piece<W>(R, (lane >> 3) + 8 * h, lane & 7, t, nvalid);
+                        if (a.ok != b.ok || (a.ok && (a.lds_off != b.lds_off || a.P != b.P))) bad++;
+                    }
+                }
+        }
+    return bad;
 }
 
 template <int L, bool XT>
@@ -98,6 +124,10 @@ void run(const uint8_t *tab, const uint8_t *pt, const uint8_t *keys, int per_blo
                 st[b][w] = emit_head<L>(s, ptw, rk[b * 44 + w]);
             }
         uint8_t *gx = x + (size_t)G::XS * blk0, *gy = y + (size_t)G::YS * blk0, *gz = z + (size_t)G::ZS * blk0;
+        std::vector<FlushState<WX>> fx(64);
+        std::vector<FlushState<WY>> fy(64);
+        std::vector<FlushState<WZ>> fz(64);
+        for (int lane = 0; lane < 64; ++lane) { fx[lane].init(lane, nvalid); fy[lane].init(lane, nvalid); fz[lane].init(lane, nvalid); }
         for (int R = 1; R <= 9; ++R) {
             for (int b = 0; b < BPW; ++b) {
                 for (int w = 0; w < 4; ++w) { auto s = sink(b, w); sub[w] = emit_sbox<L>(s, WX::woff(R), WY::woff(R), WZ::woff(R), st[b][w], T); }
@@ -113,9 +143,9 @@ void run(const uint8_t *tab, const uint8_t *pt, const uint8_t *keys, int per_blo
                     }
                 }
             }
-            flush_col<WX>(R, sx, gx, nvalid);
-            flush_col<WY>(R, sy, gy, nvalid);
-            flush_col<WZ>(R, sz, gz, nvalid);
+            flush_col<WX>(R, sx, gx, fx);
+            flush_col<WY>(R, sy, gy, fy);
+            flush_col<WZ>(R, sz, gz, fz);
         }
     }
 }
@@ -146,4 +176,9 @@ extern "C" void lane_model_window(int layout, int col, int out[6]) {
     };
     if (layout == DENSE) { if (col == 0) fill(WinX<DENSE>{}); else if (col == 1) fill(WinY<DENSE>{}); else fill(WinZ<DENSE>{}); }
     else { if (col == 0) fill(WinX<PACKED>{}); else if (col == 1) fill(WinY<PACKED>{}); else fill(WinZ<PACKED>{}); }
+}
+
+extern "C" int lane_model_flush_forms_disagree(void) {
+    return flush_forms_disagree<WinX<DENSE>>() + flush_forms_disagree<WinY<DENSE>>() + flush_forms_disagree<WinZ<DENSE>>() +
+           flush_forms_disagree<WinX<PACKED>>() + flush_forms_disagree<WinY<PACKED>>() + flush_forms_disagree<WinZ<PACKED>>();
 }

@@ -116,6 +116,12 @@ def test_window_geometry(model):
         assert len(banks) == 8 and all(v % 4 == 0 for v in banks)
 
 
+def test_flush_incremental_equals_closed_form(model):
+    """The kernel's incremental flush index math (FlushState) == the closed form (flush_piece) for every
+    round, lane, piece and number of valid blocks, in all six column geometries."""
+    assert model.lane_model_flush_forms_disagree() == 0
+
+
 def test_golden_vectors(model, oracle):
     from pathlib import Path
     g = np.load(Path(__file__).resolve().parent / "golden" / "slab_vectors.npz")
