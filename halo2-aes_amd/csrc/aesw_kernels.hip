@@ -226,9 +226,10 @@ struct Stage {
     static constexpr int RK_BYTES_W = BPW * RK_BYTES;  // per-block round keys of a wave
 };
 
-template <int L> __host__ __device__ constexpr int enc_wave_lds(bool pbk, bool kemit) {
-    return ((kemit && Stage<L>::KEY_BYTES > Stage<L>::ENC_BYTES) ? Stage<L>::KEY_BYTES : Stage<L>::ENC_BYTES) +
-           (pbk ? Stage<L>::RK_BYTES_W : 0);
+// The key staging (per-block keys with key witness) aliases the encrypt windows: the key slab has
+// left LDS before the first round writes.  Round keys live in registers in every key mode.
+template <int L> __host__ __device__ constexpr int enc_wave_lds(bool kemit) {
+    return (kemit && Stage<L>::KEY_BYTES > Stage<L>::ENC_BYTES) ? Stage<L>::KEY_BYTES : Stage<L>::ENC_BYTES;
 }
 
 // One key-schedule round for every quad of the wave.
@@ -238,15 +239,17 @@ __device__ __forceinline__ uint32_t key_round_dev(KS &ks, int rho, int w, uint32
     return emit_key_round<L>(ks, rho, w, k0, k1, k2, k3, rcon(rho - 1), tab);
 }
 
-// Key phase of a wave: W[0..15] = key, ten rounds, round keys to rkl[blk][44].
-template <int L, bool EMIT, class T>
+// Key phase of a wave: W[0..15] = key, ten rounds; this lane's word of every round key goes to
+// rk[0..10] (registers) and, when rkl is given, also to LDS rkl[blk][44] (key_kernel's rk output).
+template <int L, bool EMIT, bool TO_LDS, class T>
 __device__ __forceinline__ void key_phase(uint8_t *lds, uint32_t stage, uint32_t rk_off, uint32_t key_word, int blk,
-                                          int w, const T &tab) {
+                                          int w, const T &tab, uint32_t (&rk)[11]) {
     using G = Geo<L>;
     using St = Stage<L>;
     uint32_t *rkl = reinterpret_cast<uint32_t *>(lds + rk_off) + blk * 44 + w;
     uint32_t kw = key_word;
-    rkl[0] = kw;
+    rk[0] = kw;
+    if (TO_LDS) rkl[0] = kw;
     if (EMIT) {
         DevKSink ks{lds, stage + St::KX + blk * G::KXS, stage + St::KY + blk * G::KYS, stage + St::KZ + blk * G::KZS,
                     stage + St::KW + blk * WORDS_ROWS};
@@ -254,14 +257,16 @@ __device__ __forceinline__ void key_phase(uint8_t *lds, uint32_t stage, uint32_t
 #pragma unroll
         for (int rho = 1; rho <= 10; ++rho) {
             kw = key_round_dev<L>(ks, rho, w, kw, tab);
-            rkl[4 * rho] = kw;
+            rk[rho] = kw;
+            if (TO_LDS) rkl[4 * rho] = kw;
         }
     } else {
         NullKSink ks;
 #pragma unroll
         for (int rho = 1; rho <= 10; ++rho) {
             kw = key_round_dev<L>(ks, rho, w, kw, tab);
-            rkl[4 * rho] = kw;
+            rk[rho] = kw;
+            if (TO_LDS) rkl[4 * rho] = kw;
         }
     }
 }
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using G = Geo<L>;
     using St = Stage<L>;
-    constexpr int WAVE_LDS = enc_wave_lds<L>(PBK, KEMIT);
+    constexpr int WAVE_LDS = enc_wave_lds<L>(KEMIT);
 
     const int tid = threadIdx.x;
     const int lane0 = tid & 63;
@@ -322,7 +327,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
         const uint64_t b0 = group_blk0(blockIdx.x);
         if ((lane0 >> 2) < group_nvalid(b0)) ptw_first = reinterpret_cast<const uint32_t *>(a.pt)[(b0 + (lane0 >> 2)) * 4 + w];
     }
-    uint32_t rkr[11];  // KM_PRE: this lane's word of every round key
+    uint32_t rkr[11];  // this lane's word of every round key (KM_PRE: loaded here; KM_PBK: key phase)
     if (KM == KM_PRE) {
 #pragma unroll
         for (int r = 0; r < 11; ++r) rkr[r] = a.rk[4 * r + w];
@@ -358,7 +363,6 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
         uint32_t stage = stage0;
         asm volatile("" : "+v"(lane), "+v"(stage));
         const int blk = lane >> 2;
-        const uint32_t rk_w = stage + (WAVE_LDS - St::RK_BYTES_W);  // PBK only: tail of the slab
         const uint64_t blk0 = group_blk0(grp);
         const int nvalid = group_nvalid(blk0);
         if (nvalid == 0) continue;
@@ -369,16 +373,15 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
 
         if (PBK) {
             const uint32_t kw = live ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
-            key_phase<L, KEMIT>(lds, stage, rk_w, kw, blk, w, tab);
+            key_phase<L, KEMIT, false>(lds, stage, 0, kw, blk, w, tab, rkr);
             if (KEMIT) {
                 wave_lds_fence();
                 key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
             }
             wave_lds_fence();
         }
-        const uint32_t *rkp = PBK ? reinterpret_cast<const uint32_t *>(lds + rk_w) + blk * 44 + w
-                                  : reinterpret_cast<const uint32_t *>(lds + shared_rk) + w;
-        auto rkw = [&](int r) -> uint32_t { return KM == KM_PRE ? rkr[r] : rkp[4 * r]; };
+        const uint32_t *rkp = reinterpret_cast<const uint32_t *>(lds + shared_rk) + w;  // KM_SHARED
+        auto rkw = [&](int r) -> uint32_t { return KM == KM_SHARED ? rkp[4 * r] : rkr[r]; };
 
         DevSink<L> s;
         s.lds = lds;
@@ -450,7 +453,8 @@ __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     const int nvalid = left >= BPW ? BPW : (left > 0 ? (int)left : 0);
     if (nvalid == 0) return;
     const uint32_t kw = blk < nvalid ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
-    key_phase<L, true>(lds, stage, rk_w, kw, blk, w, tab);
+    uint32_t rk_unused[11];
+    key_phase<L, true, true>(lds, stage, rk_w, kw, blk, w, tab, rk_unused);
     wave_lds_fence();
     key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
     if (a.rk) flush_contig<16, RK_BYTES, NT>(lds, rk_w, a.rk + blk0 * RK_BYTES, nvalid, lane);
@@ -598,7 +602,7 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
     p.ngroups = (uint32_t)groups;
     p.xcd_remap = xr ? 1u : 0u;
     const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
-    const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KM == KM_PBK, KEMIT);
+    const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KEMIT);
     auto k = encrypt_kernel<L, XT, KM, KEMIT, NT>;
     {
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k), lds);
