@@ -65,6 +65,7 @@ SYMBOLS = {
     "aesw_assemble_advice_device": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
     "aesw_encrypt_witness": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab)]),
     "aesw_key_schedule_witness": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P]),
+    "aesw_encrypt_witness_stream": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P]),
     "aesw_lookup_table": (_I, [_P, _P, _P, _P, _P]),
     "aesw_host_alloc": (_P, [C.c_size_t]),
     "aesw_host_free": (None, [_P]),
@@ -447,6 +448,34 @@ class Context:
                                             _np_ptr(ct) if ct is not None else None, C.byref(ks) if ks is not None else None)
         self._check(rc, "aesw_encrypt_witness")
         return Witness(cols[0], cols[1], cols[2], ct, key)
+
+    def encrypt_witness_stream(self, pt: np.ndarray, keys, consume, layout: int = K.LAYOUT_PACKED):
+        """aesw_encrypt_witness_stream: consume(first_block, n_blocks, x, y, z) is called per chunk with
+        numpy views of page-locked buffers (valid only during the call) while the next chunk is in flight."""
+        pt = np.ascontiguousarray(pt, dtype=np.uint8).reshape(-1, 16)
+        n = pt.shape[0]
+        pbk = 0
+        if keys is not None:
+            keys = np.ascontiguousarray(keys, dtype=np.uint8)
+            pbk = 0 if keys.size == 16 else 1
+        strides = [column_stride(layout, c) for c in range(3)]
+        err = []
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8))
+        def cb(_user, first, count, x, y, z):
+            try:
+                cols = [np.ctypeslib.as_array(p, shape=(count * s,)) for p, s in zip((x, y, z), strides)]
+                r = consume(int(first), int(count), *cols)
+                return int(r or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                err.append(e)
+                return 1
+
+        rc = self._lib.aesw_encrypt_witness_stream(self._h, _np_ptr(pt), _np_ptr(keys) if keys is not None else None, pbk, n,
+                                                   layout, C.cast(cb, C.c_void_p), None)
+        if err:
+            raise err[0]
+        self._check(rc, "aesw_encrypt_witness_stream")
 
     def key_schedule_witness_host(self, keys: np.ndarray, layout: int = K.LAYOUT_PACKED) -> KeyWitness:
         keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 16)

@@ -646,6 +646,87 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
     return AESW_OK;
 }
 
+int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys, uint64_t n, int layout,
+                                aesw_chunk_fn consume, void *user) {
+    if (!ctx || !valid_layout(layout) || !consume) return AESW_ERR_INVALID_ARG;
+    if (n == 0) return AESW_OK;
+    if (!pt || (!keys && per_block_keys)) return AESW_ERR_INVALID_ARG;
+    if (!keys && !ctx->have_key) return AESW_ERR_NO_KEY;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    int rc = ensure_streams(ctx);
+    if (rc != AESW_OK) return rc;
+    const size_t strides[3] = {aesw_column_stride(layout, 0), aesw_column_stride(layout, 1), aesw_column_stride(layout, 2)};
+    const bool pbk = per_block_keys != 0;
+    uint64_t chunk = (uint64_t)ctx->chunk_blocks;
+    if (chunk > n) chunk = n;
+    chunk = (chunk + 63) / 64 * 64;
+    // device scratch: inputs + two sets of columns; page-locked bounce: two sets of columns
+    size_t off = 0, col_off[2][3], boff[3], bneed = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_pt = take(n * 16), o_keys = take(pbk ? n * 16 : 16);
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 3; ++c) col_off[s][c] = take(chunk * strides[c]);
+    for (int c = 0; c < 3; ++c) { boff[c] = bneed; bneed += (chunk * strides[c] + 255) / 256 * 256; }
+    rc = ensure_scratch(ctx, off);
+    if (rc != AESW_OK) return rc;
+    rc = ensure_bounce(ctx, bneed);
+    if (rc != AESW_OK) return rc;
+    uint8_t *d = ctx->scratch;
+    struct SyncGuard {
+        aesw_ctx *c;
+        ~SyncGuard() { (void)hipStreamSynchronize(c->s_copy); (void)hipStreamSynchronize(c->s_compute); }
+    } sync_guard{ctx};
+    HIP_TRY(ctx, hipMemcpyAsync(d + o_pt, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
+    if (keys) HIP_TRY(ctx, hipMemcpyAsync(d + o_keys, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
+    hipEvent_t done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    struct EvGuard {
+        hipEvent_t *a, *b;
+        ~EvGuard() { for (int i = 0; i < 2; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } }
+    } evg{done, copied};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+    }
+    uint64_t first[2] = {0, 0}, count[2] = {0, 0};
+    bool busy[2] = {false, false};
+    auto issue = [&](int s, uint64_t b0, uint64_t m) -> int {
+        int r = aesw_encrypt_witness_device(ctx, d + o_pt + 16 * b0, !keys ? nullptr : (pbk ? d + o_keys + 16 * b0 : d + o_keys), per_block_keys, m,
+                                            layout, d + col_off[s][0], d + col_off[s][1], d + col_off[s][2], nullptr, nullptr, ctx->s_compute);
+        if (r != AESW_OK) return r;
+        HIP_TRY(ctx, hipEventRecord(done[s], ctx->s_compute));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
+        for (int c = 0; c < 3; ++c)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[s] + boff[c], d + col_off[s][c], m * strides[c], hipMemcpyDeviceToHost, ctx->s_copy));
+        HIP_TRY(ctx, hipEventRecord(copied[s], ctx->s_copy));
+        first[s] = b0; count[s] = m; busy[s] = true;
+        return AESW_OK;
+    };
+    // two stages in flight: while the host consumes stage s, stage s^1 is computed and copied
+    uint64_t b0 = 0;
+    int it = 0;
+    for (; it < 2 && b0 < n; ++it) {
+        const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
+        rc = issue(it, b0, m);
+        if (rc != AESW_OK) return rc;
+        b0 += m;
+    }
+    for (int s = 0;; s ^= 1) {
+        if (!busy[s]) break;
+        HIP_TRY(ctx, hipEventSynchronize(copied[s]));
+        busy[s] = false;
+        if (consume(user, first[s], count[s], ctx->bounce[s] + boff[0], ctx->bounce[s] + boff[1], ctx->bounce[s] + boff[2]) != 0)
+            return AESW_ERR_MISMATCH;
+        if (b0 < n) {
+            const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
+            rc = issue(s, b0, m);
+            if (rc != AESW_OK) return rc;
+            b0 += m;
+        }
+    }
+    return AESW_OK;
+}
+
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout, uint8_t *w, uint8_t *kx,
                               uint8_t *ky, uint8_t *kz, uint8_t *rk) {
     if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;

@@ -174,6 +174,17 @@ void aesw_host_free(void *p);
 int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys,
                          uint64_t n, int layout, uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct,
                          const aesw_key_slab *key_slab);
+/* Streaming form (BASELINE.json configs[4]: D2H overlapped with the host's assign loop): the batch
+ * is produced chunk by chunk; `consume` is called on the calling thread for each chunk, in block
+ * order, with page-locked buffers holding the chunk's columns, WHILE the next chunk's kernel and
+ * D2H are in flight.  The pointers are valid only during the call.  A non-zero return from
+ * `consume` aborts the stream and is returned as AESW_ERR_MISMATCH.  keys as in
+ * aesw_encrypt_witness (NULL = scheduled key). */
+typedef int (*aesw_chunk_fn)(void *user, uint64_t first_block, uint64_t n_blocks, const uint8_t *x,
+                             const uint8_t *y, const uint8_t *z);
+int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys,
+                                int per_block_keys, uint64_t n, int layout, aesw_chunk_fn consume,
+                                void *user);
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout,
                               uint8_t *w, uint8_t *kx, uint8_t *ky, uint8_t *kz, uint8_t *rk);
 /* host-pointer aesw_schedule_key_device: key is 16 host bytes, key_slab host buffers (optional) */

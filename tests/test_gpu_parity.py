@@ -371,6 +371,40 @@ def test_host_pointer_path_pinned_outputs(ctx, pkg, oracle):
         ctx.set_option("chunk_blocks", 1 << 15)
 
 
+def test_streaming_host_path(ctx, pkg, oracle):
+    """aesw_encrypt_witness_stream (BASELINE configs[4] shape): chunks arrive in order while the next is in flight."""
+    import torch
+    pt, keys = _inputs(5000)
+    ctx.set_option("chunk_blocks", 1024)
+    try:
+        for layout in (ol.DENSE, ol.PACKED):
+            strides = ol.ENC_STRIDE[layout]
+            for k_host in (None, keys[3], keys):
+                if k_host is None:
+                    ctx.schedule_key(torch.from_numpy(keys[3]).cuda(), layout=layout, key_slab=False)
+                    torch.cuda.synchronize()
+                got = [np.zeros(5000 * s, np.uint8) for s in strides]
+                seen = []
+
+                def consume(first, count, x, y, z):
+                    seen.append((first, count))
+                    for dst, src, s in zip(got, (x, y, z), strides):
+                        dst[first * s:(first + count) * s] = src
+                    return 0
+
+                ctx.encrypt_witness_stream(pt, k_host, consume, layout=layout)
+                assert seen == [(i, min(1024, 5000 - i)) for i in range(0, 5000, 1024)]
+                exp = oracle.encrypt_witness(pt, keys[3] if k_host is None else k_host, layout=layout)
+                for c, g in zip("xyz", got):
+                    _cmp(c, g, getattr(exp, c))
+        # the consumer can abort the stream
+        with pytest.raises(pkg.AeswError) as e:
+            ctx.encrypt_witness_stream(pt, keys[3], lambda *a: 1, layout=ol.PACKED)
+        assert e.value.status == 7
+    finally:
+        ctx.set_option("chunk_blocks", 1 << 15)
+
+
 def test_argument_errors(ctx, pkg):
     import torch
     pt = torch.zeros((4, 16), dtype=torch.uint8, device="cuda")
