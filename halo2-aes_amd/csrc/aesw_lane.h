@@ -10,7 +10,7 @@
 // The functions are __host__ __device__ so the same source is exercised on the
 // CPU by tests/lane_model (perm() is emulated there) against the oracle before
 // any GPU time is spent.  They never touch memory directly: a Sink supplies
-//   plain<COL>(off, v): dword v at segment-relative byte offset off + 4*w
+//   plain<COL>(off, v): dword v at staging-window byte offset off + 4*w (Win<>::woff(R) + row offset)
 //   mix<COL>(off, k, v): dword k of this lane's lcon() record group
 // which is LDS on the device and the output arrays in the host model.
 #pragma once
@@ -97,7 +97,7 @@ AESW_HD uint32_t emit_head(S &s, uint32_t ptw, uint32_t rk0w) {
 }
 
 // SubBytes rows of a round (src/aes128.rs:203-209 -> sbox_chip.rs:57-83):
-// x = state byte, y = S_BOX[x].  rel* = where this round starts in the segment.
+// x = state byte, y = S_BOX[x].  rel* = where this round starts in the block's staging window.
 template <int L, class S, class T>
 AESW_HD uint32_t emit_sbox(S &s, int relx, int rely, int relz, uint32_t st, const T &tab) {
     using G = Geo<L>;
