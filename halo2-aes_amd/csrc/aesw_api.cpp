@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -300,7 +301,13 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "waves_shared")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_shared = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "waves_pbk")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_pbk = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "nt_stores")) { ctx->nt = value != 0 ? 1 : 0; return AESW_OK; }
-    if (!std::strcmp(name, "store_mode")) { if (value < 0 || value > 3) return AESW_ERR_INVALID_ARG; ctx->nt = (int)value; return AESW_OK; }  // 3 = diagnostic: no flush, wrong output
+    if (!std::strcmp(name, "store_mode")) {
+        // 3 = diagnostic build of the flush (no stores, output is garbage): tools/ only, behind an env switch
+        const int max_mode = std::getenv("AESW_DIAGNOSTIC") ? 3 : 2;
+        if (value < 0 || value > max_mode) return AESW_ERR_INVALID_ARG;
+        ctx->nt = (int)value;
+        return AESW_OK;
+    }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
     if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }

@@ -125,7 +125,8 @@ int aesw_selector_tags(uint8_t enc_tag[AESW_AES_ROWS], uint8_t key_tag[AESW_KEY_
  * aesw_encrypt_witness_device(..., d_keys = NULL, per_block_keys = 0) calls,
  * and optionally emits its key-schedule witness (one key slab).  This is the
  * reference's call shape: schedule_key once, encrypt many times
- * (benches/aes128.rs:50-53). */
+ * (benches/aes128.rs:50-53).  The round keys are written on `stream`: later
+ * encrypt calls must run on the same stream or after it has been synchronised. */
 int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout,
                              const aesw_key_slab *d_key_slab, void *stream);
 /* d_keys: n*16 B when per_block_keys; 16 B (one key, expanded inside the call)

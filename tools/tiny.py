@@ -1,4 +1,5 @@
-import sys, statistics
+import os, sys, statistics
+os.environ.setdefault('AESW_DIAGNOSTIC', '1')  # allows store_mode=3 (flush left out)
 sys.path.insert(0,".")
 import torch, __graft_entry__ as ge
 ge.build(); pkg=ge.load_package()
