@@ -425,3 +425,18 @@ def test_argument_errors(ctx, pkg):
     out = ctx.encrypt_witness(torch.zeros((0, 16), dtype=torch.uint8, device="cuda"),
                               torch.zeros(16, dtype=torch.uint8, device="cuda"))
     assert out.x.numel() == 0
+
+
+def test_plain_c_host(pkg, tmp_path):
+    """The C ABI from a plain C program (gcc, no Python/torch in the process): examples/aesw_demo.c."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "aesw_demo"
+    lib_dir = root / "halo2-aes_amd"
+    subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-I", str(root / "include"), str(root / "examples" / "aesw_demo.c"),
+                    "-o", str(exe), "-L", str(lib_dir), "-laesw", "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True)
+    out = subprocess.run([str(exe), "20000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "66e94bd4ef8a2c3b884cfa59ca342b2e" in out.stdout and "ok" in out.stdout
