@@ -303,8 +303,13 @@ def main():
             dt = time.perf_counter() - t0
             regions = hc.num_regions
             hc.close()
+            t0 = time.perf_counter()
+            hc = pkg.HostCircuit.aes(ctx, k, n_sets, hkey, hpt, bulk_assign=True)
+            dtb = time.perf_counter() - t0
+            hc.close()
             extras["host_synthesize"] = {"circuit": "FixedAes128Config<20,3>, %d blocks (full)" % nn, "seconds": dt,
                                          "blocks_per_s": nn / dt, "regions_per_s": regions / dt,
+                                         "bulk_assign_blocks_per_s": nn / dtb,
                                          "note": "C++ host mirror: table + schedule_key + encrypt() per block, one thread, "
                                                  "device witness generation included (negligible)"}
         except Exception as e:

@@ -76,7 +76,8 @@ SYMBOLS = {
 
 # include/aesw_host.h: the host-side mirror of the reference's circuits
 HOST_SYMBOLS = {
-    "aesw_host_aes_circuit_run": (_I, [_P, _U32, _U32, _P, _P, _U64, _I, _I, C.POINTER(_P)]),
+    "aesw_host_aes_circuit_run": (_I, [_P, _U32, _U32, _P, _P, _U64, _I, _I, _I, C.POINTER(_P)]),
+    "aesw_host_circuit_copies": (_I, [_P, _P]),
     "aesw_host_key_circuit_run": (_I, [_P, _U32, _P, C.POINTER(_P)]),
     "aesw_host_circuit_free": (None, [_P]),
     "aesw_host_circuit_verify": (_I, [_P, C.c_char_p, C.c_size_t]),
@@ -504,14 +505,15 @@ class HostCircuit:
 
     @classmethod
     def aes(cls, ctx: "Context", k: int, n_sets: int, key, pts, with_witnesses: bool = True,
-            skip_schedule_key: bool = False) -> "HostCircuit":
+            skip_schedule_key: bool = False, bulk_assign: bool = False) -> "HostCircuit":
         """load_enc_full_table, schedule_key(key), encrypt(pts[b]) for every block: TestAesCircuit /
         Aes128BenchCircuit (src/aes128.rs:376-407, benches/aes128.rs:30-61)."""
         key = np.ascontiguousarray(key, np.uint8).reshape(16)
         pts = np.ascontiguousarray(pts, np.uint8).reshape(-1, 16)
         h = C.c_void_p()
         rc = ctx._lib.aesw_host_aes_circuit_run(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0],
-                                                1 if with_witnesses else 0, 1 if skip_schedule_key else 0, C.byref(h))
+                                                1 if with_witnesses else 0, 1 if skip_schedule_key else 0,
+                                                1 if bulk_assign else 0, C.byref(h))
         if rc:
             raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
         return cls(ctx._lib, h.value)
@@ -569,6 +571,14 @@ class HostCircuit:
         n = C.c_uint64()
         p = self._lib.aesw_host_circuit_table(self._h, col, C.byref(n))
         return self._arr(p, n.value)
+
+    def copies(self) -> np.ndarray:
+        """[num_copies, 4] = (copy column, copy row, original column, original row)."""
+        out = np.zeros((self.num_copies, 4), np.uint64)
+        rc = self._lib.aesw_host_circuit_copies(self._h, _np_ptr(out))
+        if rc:
+            raise AeswError(rc)
+        return out
 
     def ciphertext(self, b):
         ct = np.zeros(16, np.uint8)

@@ -351,6 +351,13 @@ public:
         have_keys = true;
     }
 
+    // Bulk assignment: after the first block has gone through the reference's
+    // 1 360 one-row regions, every later block is ONE region of 1 360 rows whose cells are the device
+    // bytes, whose selectors come from aesw_selector_tags() and whose copy constraints replay the
+    // first block's (block-relative) copy graph.  Same cells, selectors and equality constraints
+    // as the per-region path (tests compare them), without 1 360 shape+assign double passes per block.
+    bool bulk_assign = false;
+
     // :154-265
     std::vector<AssignedCell> encrypt(Layouter &layouter, const uint8_t plaintext[16]) {
         if (!aes_callable()) throw Panic(Panic::Capacity, "AES calls too many. doesn't fit in the rows");  // :159-162
@@ -361,6 +368,104 @@ public:
         if (b >= wit->n) throw Error(Error::Mismatch, "more encrypt() calls than blocks in the device witness");
         if (std::memcmp(plaintext, wit->pt.data() + 16 * b, 16) != 0) throw Error(Error::Mismatch, "plaintext differs from the device witness's block");
         cur = WitnessCursor{wit->x.data() + b * AES_ROWS_, wit->y.data() + b * AES_ROWS_, wit->z.data() + b * AES_ROWS_, 0, AES_ROWS_};
+        if (bulk_assign && graph_ready) return encrypt_bulk(layouter);
+        const size_t copies_before = layouter.copies().size();
+        const uint64_t block_start = layouter.column_height(get_advices()[0]);
+        std::vector<AssignedCell> out = encrypt_regions(layouter);
+        if (bulk_assign) record_copy_graph(layouter, copies_before, block_start);
+        return out;
+    }
+
+private:
+    struct CopyEdge {
+        uint8_t dst_col;   // 0..2 within the set
+        uint16_t dst_row;  // block-relative
+        bool from_key;     // source is a round-key cell (round, idx) instead of a block cell
+        uint8_t src_col;
+        uint16_t src_row;
+        uint8_t key_round, key_idx;
+    };
+    std::vector<CopyEdge> graph;
+    bool graph_ready = false;
+
+    void record_copy_graph(const Layouter &layouter, size_t first, uint64_t block_start) {
+        const Column *adv = get_advices();
+        auto rel_col = [&](const Cell &c) -> int {
+            for (int j = 0; j < 3; ++j)
+                if (c.column.type == Any::Advice && c.column.index == adv[j].index) return j;
+            return -1;
+        };
+        graph.clear();
+        const auto &copies = layouter.copies();
+        for (size_t i = first; i < copies.size(); ++i) {
+            const Cell &dst = copies[i].first, &src = copies[i].second;
+            CopyEdge e{};
+            const int dc = rel_col(dst);
+            if (dc < 0 || dst.row < block_start || dst.row >= block_start + AES_ROWS_) throw Error(Error::Synthesis, "copy target outside the block");
+            e.dst_col = (uint8_t)dc;
+            e.dst_row = (uint16_t)(dst.row - block_start);
+            const int sc = rel_col(src);
+            if (sc >= 0 && src.row >= block_start && src.row < block_start + AES_ROWS_) {
+                e.from_key = false;
+                e.src_col = (uint8_t)sc;
+                e.src_row = (uint16_t)(src.row - block_start);
+            } else {
+                bool found = false;
+                for (size_t r = 0; r < keys.size() && !found; ++r)
+                    for (size_t j = 0; j < keys[r].size() && !found; ++j) {
+                        const Cell &kc = keys[r][j].cell;
+                        if (kc.column.type == src.column.type && kc.column.index == src.column.index && kc.row == src.row) {
+                            e.from_key = true;
+                            e.key_round = (uint8_t)r;
+                            e.key_idx = (uint8_t)j;
+                            found = true;
+                        }
+                    }
+                if (!found) throw Error(Error::Synthesis, "copy source is neither a block cell nor a round-key cell");
+            }
+            graph.push_back(e);
+        }
+        // fixed per-row data of a block: which cells exist, which selector is on
+        for (int c = 0; c < 3; ++c) aesw_packed_index(c, pidx[c]);
+        aesw_selector_tags(tags, nullptr, nullptr, nullptr);
+        graph_ready = true;
+    }
+
+    std::vector<AssignedCell> encrypt_bulk(Layouter &layouter) {
+        const Column *adv = get_advices();
+        const WitnessCursor *c = &cur;
+        const Selector sel_of_tag[6] = {Selector{}, range_configs.at(current).q, xor_config().q, sbox_config().q,
+                                        mul2_config().q, mul3_config().q};
+        std::vector<AssignedCell> out = layouter.assign_region<std::vector<AssignedCell>>("AES block (bulk)", [&](Region &region) {
+            std::vector<Cell> cells[3];
+            for (auto &v : cells) v.resize(AES_ROWS_);
+            std::vector<AssignedCell> ct;
+            for (uint64_t r = 0; r < AES_ROWS_; ++r) {
+                if (tags[r]) region.enable_selector(sel_of_tag[tags[r]], r);
+                cells[0][r] = region.assign_advice(adv[0], r, [c, r] { return Value::of(c->x[r]); }).cell;
+                if (pidx[1][r] >= 0) cells[1][r] = region.assign_advice(adv[1], r, [c, r] { return Value::of(c->y[r]); }).cell;
+                if (pidx[2][r] >= 0) {
+                    AssignedCell z = region.assign_advice(adv[2], r, [c, r] { return Value::of(c->z[r]); });
+                    cells[2][r] = z.cell;
+                    if (r >= AES_ROWS_ - 16) ct.push_back(z);
+                }
+            }
+            for (const CopyEdge &e : graph) {
+                const Cell &dst = cells[e.dst_col][e.dst_row];
+                const Cell &src = e.from_key ? keys[e.key_round][e.key_idx].cell : cells[e.src_col][e.src_row];
+                region.constrain_equal(dst, src);
+            }
+            return ct;
+        });
+        cur.row = AES_ROWS_;
+        return out;
+    }
+
+    int32_t pidx[3][AESW_AES_ROWS];
+    uint8_t tags[AESW_AES_ROWS];
+
+    // the reference's body of encrypt(): :176-265
+    std::vector<AssignedCell> encrypt_regions(Layouter &layouter) {
 
         const U8XorChip xor_chip = U8XorChip::construct(xor_config(), &cur);
         const SboxChip sbox_chip = SboxChip::construct(sbox_config(), &cur);
@@ -404,6 +509,7 @@ public:
         return prev_round;
     }
 
+public:
     Aes128KeyScheduleConfig key_schedule_config;
     std::vector<std::array<Column, 3>> advices;
     TableColumn tables[4];

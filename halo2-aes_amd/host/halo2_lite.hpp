@@ -155,6 +155,7 @@ public:
         assignment(t);
     }
     uint64_t column_height(Column c) const { return c.type == Any::Advice ? h_adv_.at(c.index) : h_fix_.at(c.index); }
+    const std::vector<std::pair<Cell, Cell>> &copies() const { return a_.copies; }  // (copy, original) pairs so far
 
 private:
     struct RegionColumn {

@@ -75,6 +75,7 @@ struct AesCircuit {
     uint8_t key[16];
     std::vector<uint8_t> plaintexts;
     bool skip_schedule_key = false;
+    bool bulk_assign = false;
     std::shared_ptr<const AesWitness> witness;  // computed lazily, once
     std::vector<std::vector<AssignedCell>> outputs;
 
@@ -83,6 +84,7 @@ struct AesCircuit {
         const uint64_t n = plaintexts.size() / 16;
         if (!witness) witness = AesWitness::generate(ctx, key, plaintexts.data(), n);
         config.attach_witness(witness);
+        config.bulk_assign = bulk_assign;
         load_enc_full_table(layouter, config.tables, ctx);
         if (!skip_schedule_key) config.schedule_key(layouter, key);
         for (uint64_t b = 0; b < n; ++b) outputs.push_back(config.encrypt(layouter, plaintexts.data() + 16 * b));
@@ -153,11 +155,11 @@ extern "C" {
 const char *aesw_host_last_error(void) { return g_last_error.c_str(); }
 
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16], const uint8_t *pts, uint64_t n,
-                              int with_witnesses, int skip_schedule_key, aesw_host_circuit **out) {
+                              int with_witnesses, int skip_schedule_key, int bulk_assign, aesw_host_circuit **out) {
     if (!ctx || !key || (n && !pts) || !out || k < 11 || k > 26 || n_sets == 0 || n_sets > 64) return AESW_ERR_INVALID_ARG;
     *out = nullptr;
     return guarded([&] {
-        AesCircuit circuit{ctx, k, n_sets, {0}, std::vector<uint8_t>(pts, pts + 16 * n), skip_schedule_key != 0, nullptr, {}};
+        AesCircuit circuit{ctx, k, n_sets, {0}, std::vector<uint8_t>(pts, pts + 16 * n), skip_schedule_key != 0, bulk_assign != 0, nullptr, {}};
         std::memcpy(circuit.key, key, 16);
         auto *c = new aesw_host_circuit{MockProver::run(k, circuit, with_witnesses != 0), {}};
         c->outputs = std::move(circuit.outputs);
@@ -190,6 +192,15 @@ uint64_t aesw_host_circuit_num_rows(const aesw_host_circuit *c) { return c->prov
 uint64_t aesw_host_circuit_num_regions(const aesw_host_circuit *c) { return c->prover.assembly.n_regions; }
 uint64_t aesw_host_circuit_num_copies(const aesw_host_circuit *c) { return c->prover.assembly.copies.size(); }
 uint64_t aesw_host_circuit_closure_calls(const aesw_host_circuit *c) { return c->prover.assembly.closure_calls; }
+int aesw_host_circuit_copies(const aesw_host_circuit *c, uint64_t *out) {
+    if (!c || !out) return AESW_ERR_INVALID_ARG;
+    size_t i = 0;
+    for (const auto &p : c->prover.assembly.copies) {
+        out[i++] = p.first.column.index; out[i++] = p.first.row;
+        out[i++] = p.second.column.index; out[i++] = p.second.row;
+    }
+    return AESW_OK;
+}
 const uint8_t *aesw_host_circuit_advice(const aesw_host_circuit *c, uint32_t col) {
     return col < c->prover.assembly.advice.size() ? c->prover.assembly.advice[col].data() : nullptr;
 }

@@ -28,10 +28,14 @@ typedef struct aesw_host_circuit aesw_host_circuit;
 /* load_enc_full_table, schedule_key(key), then encrypt(pts[b]) for b < n, in a
  * FixedAes128Config<K, n_sets> circuit of 2^k rows.  with_witnesses = 0 mimics
  * keygen (value closures are never evaluated).  skip_schedule_key = 1 omits
- * schedule_key() to exercise the reference's expect("Keys should be scheduled"). */
+ * schedule_key() to exercise the reference's expect("Keys should be scheduled").
+ * bulk_assign = 1: the first block goes through the reference's 1 360 one-row
+ * regions, every later block is assigned as ONE 1 360-row region that replays
+ * the first block's copy graph; cells, selectors and equality
+ * constraints are the same, only the region count differs. */
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16],
                               const uint8_t *pts, uint64_t n, int with_witnesses,
-                              int skip_schedule_key, aesw_host_circuit **out);
+                              int skip_schedule_key, int bulk_assign, aesw_host_circuit **out);
 /* key_schedule.rs TestCircuit: 3 advice columns + words_column, schedule_keys only. */
 int aesw_host_key_circuit_run(aesw_ctx *ctx, uint32_t k, const uint8_t key[16],
                               aesw_host_circuit **out);
@@ -45,6 +49,8 @@ uint64_t aesw_host_circuit_num_rows(const aesw_host_circuit *c);
 uint64_t aesw_host_circuit_num_regions(const aesw_host_circuit *c);
 uint64_t aesw_host_circuit_num_copies(const aesw_host_circuit *c);
 uint64_t aesw_host_circuit_closure_calls(const aesw_host_circuit *c);
+/* equality constraints as (copy column, copy row, original column, original row), 4 x num_copies values */
+int aesw_host_circuit_copies(const aesw_host_circuit *c, uint64_t *out);
 const uint8_t *aesw_host_circuit_advice(const aesw_host_circuit *c, uint32_t col);
 const uint8_t *aesw_host_circuit_advice_assigned(const aesw_host_circuit *c, uint32_t col);
 const uint8_t *aesw_host_circuit_selector(const aesw_host_circuit *c, uint32_t sel);

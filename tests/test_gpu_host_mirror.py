@@ -69,6 +69,34 @@ def test_random_circuit_two_sets(ctx, pkg, oracle):
                 assert np.array_equal(mock.ciphertext(b), o.ciphertext(b))
 
 
+def test_bulk_assign_equals_per_region(ctx, pkg, oracle):
+    """one 1 360-row region per block (after the first) == the reference's 1 360 one-row regions:
+    same advice cells, selectors, fixed column and the same SET of equality constraints; far fewer regions."""
+    rng = np.random.default_rng(31)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (70, 16), dtype=np.uint8)
+    with pkg.HostCircuit.aes(ctx, 16, 2, key, pts) as a, pkg.HostCircuit.aes(ctx, 16, 2, key, pts, bulk_assign=True) as b:
+        assert b.verify() == (0, "")
+        for c in range(a.num_advice):
+            assert np.array_equal(a.advice(c), b.advice(c)) and np.array_equal(a.advice_assigned(c), b.advice_assigned(c))
+        for s in range(a.num_selectors):
+            assert np.array_equal(a.selector(s), b.selector(s))
+        assert np.array_equal(a.fixed(), b.fixed())
+        ca, cb = a.copies(), b.copies()
+        assert ca.shape == cb.shape
+        key_of = lambda m: np.lexsort((m[:, 3], m[:, 2], m[:, 1], m[:, 0]))
+        assert np.array_equal(ca[key_of(ca)], cb[key_of(cb)])
+        # table(1) + key schedule(421) + first block(1345) + 69 bulk blocks, against 1345 regions per block
+        assert a.num_regions == 421 + 70 * 1345 and b.num_regions == 421 + 1345 + 69
+        for blk in (0, 1, 45, 46, 69):
+            assert np.array_equal(a.ciphertext(blk), b.ciphertext(blk))
+        b.poke(1, 400 + 1360 * 3 + 40, int(b.advice(1)[400 + 1360 * 3 + 40]) ^ 0x80)
+        assert b.verify()[0] == 8
+    with oracle.circuit(16, 2, key, pts) as o, pkg.HostCircuit.aes(ctx, 16, 2, key, pts, bulk_assign=True) as b:
+        for c in range(b.num_advice):
+            assert np.array_equal(b.advice(c), o.advice(c))
+
+
 def test_keygen_pass_evaluates_no_closure(ctx, pkg):
     """keygen_vk / keygen_pk ignore value closures: nothing is read, selectors are still laid out."""
     pts = np.zeros((3, 16), np.uint8)
