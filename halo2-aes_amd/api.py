@@ -56,6 +56,7 @@ SYMBOLS = {
     "aesw_block_placement": (_I, [_U32, _U32, _U64, C.POINTER(_U32), C.POINTER(_U64)]),
     "aesw_block_capacity": (_U64, [_U32, _U32]),
     "aesw_selector_tags": (_I, [_P, _P, _P, _P]),
+    "aesw_assemble_selectors": (_I, [_U32, _U32, _U64, _P, _P]),
     "aesw_schedule_key_device": (_I, [_P, _P, _I, C.POINTER(KeySlab), _P]),
     "aesw_schedule_key": (_I, [_P, _P, _I, C.POINTER(KeySlab)]),
     "aesw_encrypt_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P]),
@@ -186,6 +187,16 @@ def selector_tags():
     if rc:
         raise AeswError(rc)
     return e, k, q, c
+
+
+def assemble_selectors(k: int, n_sets: int, n_blocks: int):
+    """(selectors[(5*n_sets+1), 2^k], fixed[2^k]) of a whole circuit, as keygen lays them out."""
+    sel = np.zeros((5 * n_sets + 1, 1 << k), np.uint8)
+    fixed = np.zeros(1 << k, np.uint8)
+    rc = load_library().aesw_assemble_selectors(k, n_sets, n_blocks, _np_ptr(sel), _np_ptr(fixed))
+    if rc:
+        raise AeswError(rc)
+    return sel, fixed
 
 
 def device_count() -> int:

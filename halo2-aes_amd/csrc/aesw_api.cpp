@@ -294,6 +294,33 @@ int aesw_block_placement(uint32_t k, uint32_t n_sets, uint64_t b, uint32_t *set,
     return AESW_ERR_CAPACITY;
 }
 
+int aesw_assemble_selectors(uint32_t k, uint32_t n_sets, uint64_t n_blocks, uint8_t *selectors, uint8_t *fixed) {
+    if (k < 2 || k > 32 || n_sets == 0 || n_sets > 1024 || !selectors) return AESW_ERR_INVALID_ARG;
+    if (n_blocks > aesw_block_capacity(k, n_sets)) return AESW_ERR_CAPACITY;
+    const uint64_t rows = (uint64_t)1 << k;
+    uint8_t enc[AES_ROWS], key[KEY_ROWS], q[WORDS_ROWS], rc[WORDS_ROWS];
+    encrypt_selector_tags(enc);
+    key_selector_tags(key, q, rc);
+    std::memset(selectors, 0, (size_t)(5 * n_sets + 1) * rows);
+    if (fixed) std::memset(fixed, 0, rows);
+    auto sel = [&](uint32_t set, int tag) { return selectors + (size_t)(5 * set + (tag - 1)) * rows; };  // tag 1..5 = selector order
+    if (rows >= KEY_ROWS)
+        for (uint32_t r = 0; r < KEY_ROWS; ++r)
+            if (key[r]) sel(0, key[r])[r] = 1;
+    for (uint32_t r = 0; r < WORDS_ROWS && r < rows; ++r) {
+        selectors[(size_t)(5 * n_sets) * rows + r] = q[r];
+        if (fixed) fixed[r] = rc[r];
+    }
+    for (uint64_t b = 0; b < n_blocks; ++b) {
+        uint32_t set;
+        uint64_t row;
+        if (aesw_block_placement(k, n_sets, b, &set, &row) != AESW_OK) return AESW_ERR_CAPACITY;
+        for (uint32_t r = 0; r < AES_ROWS; ++r)
+            if (enc[r]) sel(set, enc[r])[row + r] = 1;
+    }
+    return AESW_OK;
+}
+
 // ---- options --------------------------------------------------------------------
 
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {

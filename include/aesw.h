@@ -115,6 +115,15 @@ uint64_t aesw_block_capacity(uint32_t k, uint32_t n_sets);
 int aesw_selector_tags(uint8_t enc_tag[AESW_AES_ROWS], uint8_t key_tag[AESW_KEY_ROWS],
                        uint8_t q_eq_rcon[AESW_WORDS_ROWS], uint8_t rcon_fixed[AESW_WORDS_ROWS]);
 
+/* The selector columns and the fixed round-constant column of a whole
+ * FixedAes128Config<K, n_sets> circuit holding n_blocks encrypt() calls, as
+ * keygen lays them out (configure() order: per set range, xor, sbox, mul2, mul3
+ * (src/aes128.rs:63-68), then q_eq_rcon (src/key_schedule.rs:50)): selectors is
+ * (5*n_sets+1) columns of 2^k bytes (0/1), fixed is 2^k bytes.  Pure host,
+ * input independent.  AESW_ERR_CAPACITY when n_blocks does not fit. */
+int aesw_assemble_selectors(uint32_t k, uint32_t n_sets, uint64_t n_blocks, uint8_t *selectors,
+                            uint8_t *fixed);
+
 /* ---- device-pointer entry points (asynchronous on `stream`) -------------- */
 /* stream is a hipStream_t passed as void* (NULL = the default stream).
  * All pointers are device pointers on aesw_device(ctx); column buffers must be

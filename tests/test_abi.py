@@ -131,6 +131,21 @@ def test_block_placement_sweep(pkg):
             pkg.block_placement(k, n_sets, cap)
 
 
+def test_assemble_selectors_equals_synthesize(pkg, oracle):
+    """Whole-circuit selector and fixed columns (keygen data) == what the restated synthesize() enables."""
+    k, n_sets, n = 14, 3, 30            # 2^14 rows: 10 + 12 + 12 blocks fit; 30 fills sets 0,1 and part of 2
+    assert pkg.block_capacity(k, n_sets) == 34
+    sel, fixed = pkg.assemble_selectors(k, n_sets, n)
+    with oracle.circuit(k, n_sets, np.zeros(16, np.uint8), np.zeros((n, 16), np.uint8), record_copies=False) as c:
+        assert c.status == 0 and c.num_selectors == sel.shape[0]
+        for s in range(c.num_selectors):
+            assert np.array_equal(sel[s], c.selector(s)), "selector %d" % s
+        assert np.array_equal(fixed, c.fixed())
+    with pytest.raises(pkg.AeswError) as e:
+        pkg.assemble_selectors(k, n_sets, 35)
+    assert e.value.status == 5
+
+
 def test_no_cpu_path(pkg):
     """Without a gfx950 device the library refuses to create a context."""
     import torch

@@ -427,6 +427,63 @@ def test_argument_errors(ctx, pkg):
     assert out.x.numel() == 0
 
 
+def test_structured_inputs(ctx, oracle):
+    """Non-random inputs: every byte value repeated, counters, all-ones, pt == key, pt == ~key."""
+    import torch
+    cases = []
+    v = np.arange(256, dtype=np.uint8)
+    cases.append((np.repeat(v, 16).reshape(256, 16), np.repeat(v[::-1], 16).reshape(256, 16)))
+    cases.append((np.arange(256 * 16, dtype=np.uint32).astype(np.uint8).reshape(256, 16), np.zeros((256, 16), np.uint8)))
+    cases.append((np.full((64, 16), 0xFF, np.uint8), np.full((64, 16), 0xFF, np.uint8)))
+    k = np.random.default_rng(8).integers(0, 256, (128, 16), dtype=np.uint8)
+    cases.append((k.copy(), k))           # first sbox input 0 everywhere
+    cases.append((k ^ 0xFF, k))           # first sbox input 0xff everywhere (the reference's S_BOX[255])
+    for pt, keys in cases:
+        for layout in (ol.DENSE, ol.PACKED):
+            got = ctx.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(np.ascontiguousarray(keys)).cuda(),
+                                      layout=layout, want_ct=True, key_slab=True)
+            torch.cuda.synchronize()
+            exp = oracle.encrypt_witness(pt, keys, layout=layout)
+            for c in "xyz":
+                _cmp(c, getattr(got, c), getattr(exp, c))
+            _cmp("ct", got.ct, exp.ct)
+            kexp = oracle.key_schedule_witness(keys, layout=layout)
+            for c in ("w", "kx", "ky", "kz"):
+                _cmp(c, getattr(got.key, c), getattr(kexp, c))
+
+
+def test_two_contexts_two_threads(pkg, oracle):
+    """Contexts are thread-compatible: two host threads, each with its own context and stream, at once."""
+    import threading
+    import torch
+    pt, keys = _inputs(20000)
+    results, errors = {}, []
+
+    def work(idx, layout):
+        try:
+            c = pkg.Context(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                dpt = torch.from_numpy(pt).cuda()
+                for _ in range(5):
+                    got = c.encrypt_witness(dpt, torch.from_numpy(keys[idx]).cuda(), layout=layout, want_ct=True)
+                stream.synchronize()
+                results[idx] = (layout, got.x.cpu().numpy(), got.y.cpu().numpy(), got.z.cpu().numpy())
+            c.close()
+        except Exception as e:  # surfaced in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i, l)) for i, l in ((0, ol.DENSE), (1, ol.PACKED))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for idx, (layout, x, y, z) in results.items():
+        exp = oracle.encrypt_witness(pt, keys[idx], layout=layout)
+        _cmp("x", x, exp.x); _cmp("y", y, exp.y); _cmp("z", z, exp.z)
+
+
 def test_plain_c_host(pkg, tmp_path):
     """The C ABI from a plain C program (gcc, no Python/torch in the process): examples/aesw_demo.c."""
     import subprocess
