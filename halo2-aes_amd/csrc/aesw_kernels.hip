@@ -232,6 +232,10 @@ template <int L> __host__ __device__ constexpr int enc_wave_lds(bool kemit) {
     return (kemit && Stage<L>::KEY_BYTES > Stage<L>::ENC_BYTES) ? Stage<L>::KEY_BYTES : Stage<L>::ENC_BYTES;
 }
 
+// Residency guard: two 4-wave groups of the packed shared-key kernel must fit one CU's 160 KiB
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor: 81 920 B -> 2 groups, 82 000 B -> 1).
+static_assert(TAB_BYTES + RKS_BYTES + 4 * enc_wave_lds<PACKED>(false) <= 81920, "packed windows grew: 8 waves/CU no longer fit");
+
 // One key-schedule round for every quad of the wave.
 template <int L, class KS, class T>
 __device__ __forceinline__ uint32_t key_round_dev(KS &ks, int rho, int w, uint32_t kw, const T &tab) {
