@@ -230,7 +230,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "aesw::encrypt_kernel", "launch_ms": ms_launch,
-                     "algorithmic_bytes_per_block": runner.bytes_per_block},
+                     "algorithmic_bytes_per_block": runner.bytes_per_block,
+                     "algorithmic_bytes_per_launch": runner.bytes_per_block * n,
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE, profiles/traffic.json)"},
         "achieved_hbm_GBps_all_gpus": achieved * world,
     }
 
