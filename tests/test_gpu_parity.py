@@ -497,3 +497,26 @@ def test_plain_c_host(pkg, tmp_path):
     out = subprocess.run([str(exe), "20000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode == 0, out.stdout
     assert "66e94bd4ef8a2c3b884cfa59ca342b2e" in out.stdout and "ok" in out.stdout
+
+
+def test_committed_golden_fixtures(ctx):
+    """The HIP path against tests/golden/slab_vectors.npz directly (no oracle in the loop): the reference's
+    zero vector, FIPS-197 App. B / C.1, the S_BOX[0xff] block and seeded random blocks, both layouts,
+    per-block keys with key witness and one shared key."""
+    import torch
+    from pathlib import Path
+    g = np.load(Path(__file__).resolve().parent / "golden" / "slab_vectors.npz")
+    dpt, dkeys = torch.from_numpy(g["pt"]).cuda(), torch.from_numpy(g["keys"]).cuda()
+    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed")):
+        got = ctx.encrypt_witness(dpt, dkeys, layout=layout, want_ct=True, key_slab=True)
+        shared = ctx.encrypt_witness(dpt, dkeys[4].contiguous(), layout=layout)
+        kw = ctx.key_schedule_witness(dkeys, layout=layout)
+        torch.cuda.synchronize()
+        for c in "xyz":
+            _cmp(name + " " + c, getattr(got, c), g["%s_%s" % (name, c)])
+            _cmp(name + " shared " + c, getattr(shared, c), g["%s_shared_%s" % (name, c)])
+        _cmp(name + " ct", got.ct, g["%s_ct" % name])
+        for c in ("w", "kx", "ky", "kz"):
+            _cmp(name + " " + c, getattr(got.key, c), g["%s_%s" % (name, c)])
+        _cmp(name + " rk", kw.rk, g["%s_rk" % name])
+    assert got.ct[0].cpu().numpy().tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
