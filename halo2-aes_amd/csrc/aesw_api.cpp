@@ -29,6 +29,10 @@ struct aesw_ctx {
     int nt = 2;  // store flavour: 0 plain, 1 nontemporal, 2 write-through (sc1, default: nothing left dirty in L2 at kernel end)
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
     bool xcd_remap = false;
+    int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
+#ifdef AESW_TRACE
+    uint64_t *trace = nullptr;
+#endif
     int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
     std::string last_error;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
@@ -337,6 +341,10 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
+    if (!std::strcmp(name, "lds_pad")) { if (value < 0 || value > 120 * 1024) return AESW_ERR_INVALID_ARG; ctx->lds_pad = value; return AESW_OK; }
+#ifdef AESW_TRACE
+    if (!std::strcmp(name, "trace_ptr")) { ctx->trace = reinterpret_cast<uint64_t *>(value); return AESW_OK; }
+#endif
     if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { if (value < 64) return AESW_ERR_INVALID_ARG; ctx->chunk_blocks = value; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
@@ -414,8 +422,11 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
     const int km = per_block_keys ? 0 : (d_keys ? 1 : 2);
     EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, d_x, d_y, d_z, d_ct,
                 per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n, 0, 0};
+#ifdef AESW_TRACE
+    p.trace = ctx->trace;
+#endif
     HIP_TRY(ctx, launch_encrypt(p, layout, ctx->xt, km, per_block_keys && kemit, auto_waves(ctx, layout, per_block_keys != 0),
-                                ctx->nt, (uint32_t)ctx->grid_cap, ctx->xcd_remap, s));
+                                ctx->nt, (uint32_t)ctx->grid_cap, ctx->xcd_remap, (uint32_t)ctx->lds_pad, s));
     return AESW_OK;
 }
 

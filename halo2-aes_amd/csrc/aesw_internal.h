@@ -21,6 +21,9 @@ struct EncParams {
     uint64_t n;
     uint32_t ngroups;       // block groups (16*waves blocks each); a workgroup strides over them
     uint32_t xcd_remap;     // 1: workgroups that share an XCD (id % 8) take one contiguous eighth of the groups
+#ifdef AESW_TRACE
+    uint64_t *trace;        // tools/trace.py only: 8 x u64 per wave
+#endif
 };
 
 struct KeyParams {
@@ -33,7 +36,7 @@ struct KeyParams {
 
 // key mode: 0 = per-block keys, 1 = shared key expanded in the kernel, 2 = shared key scheduled earlier (p.rk)
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, int store_mode,
-                          uint32_t max_groups_in_flight, bool xcd_remap, hipStream_t s);
+                          uint32_t max_groups_in_flight, bool xcd_remap, uint32_t lds_pad, hipStream_t s);
 hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
 struct AssembleParams {

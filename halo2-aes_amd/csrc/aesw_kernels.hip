@@ -296,6 +296,17 @@ __device__ __forceinline__ void key_flush(const uint8_t *lds, uint32_t stage, co
 //         the 44 round-key words come from global memory, no barrier for them.
 enum : int { KM_PBK = 0, KM_SHARED = 1, KM_PRE = 2 };
 
+// tools/trace.py builds a private copy with -DAESW_TRACE: every wave records the 100 MHz wall clock at
+// seven points of its first group (launch timeline study).  Not compiled into the product library.
+#ifdef AESW_TRACE
+#define AESW_TRACE_POINT(i)                                                                              \
+    do {                                                                                                 \
+        if (a.trace && lane0 == 0) a.trace[((uint64_t)(blockIdx.x * waves + wave)) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define AESW_TRACE_POINT(i) do { } while (0)
+#endif
+
 template <int L, bool XT, int KM, bool KEMIT, int NT>
 __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     constexpr bool PBK = KM == KM_PBK;
@@ -326,11 +337,15 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
         const int64_t left = (int64_t)a.n - (int64_t)b0;
         return left >= BPW ? BPW : (left > 0 ? (int)left : 0);
     };
-    uint32_t ptw_first = 0;
-    {
-        const uint64_t b0 = group_blk0(blockIdx.x);
-        if ((lane0 >> 2) < group_nvalid(b0)) ptw_first = reinterpret_cast<const uint32_t *>(a.pt)[(b0 + (lane0 >> 2)) * 4 + w];
-    }
+    AESW_TRACE_POINT(0);
+    // this lane's word of a group's 16-byte records (plaintexts / per-block keys); 0 past the batch
+    auto load_word = [&](const uint8_t *base, uint32_t grp) -> uint32_t {
+        if (grp >= a.ngroups) return 0u;
+        const uint64_t b0 = group_blk0(grp);
+        return (lane0 >> 2) < group_nvalid(b0) ? reinterpret_cast<const uint32_t *>(base)[(b0 + (lane0 >> 2)) * 4 + w] : 0u;
+    };
+    uint32_t ptw_next = load_word(a.pt, blockIdx.x);
+    uint32_t kw_next = PBK ? load_word(a.keys, blockIdx.x) : 0u;
     uint32_t rkr[11];  // this lane's word of every round key (KM_PRE: loaded here; KM_PBK: key phase)
     if (KM == KM_PRE) {
 #pragma unroll
@@ -341,6 +356,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     for (int i = tid; i < TAB_BYTES / 4; i += blockDim.x)  // groups may be as small as one wave
         reinterpret_cast<uint32_t *>(lds)[i] = reinterpret_cast<const uint32_t *>(a.tables)[i];
     __syncthreads();
+    AESW_TRACE_POINT(1);
     const Tables<XT> tab{lds};
 
     if (KM == KM_SHARED) {
@@ -371,12 +387,11 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
         const int nvalid = group_nvalid(blk0);
         if (nvalid == 0) continue;
         const bool live = blk < nvalid;
-        const uint32_t ptw = grp == blockIdx.x ? ptw_first
-                             : (live ? reinterpret_cast<const uint32_t *>(a.pt)[(blk0 + blk) * 4 + w] : 0u);
+        const uint32_t ptw = ptw_next;
         if (grp != blockIdx.x) wave_lds_fence();  // the previous group's flush reads precede this group's writes
 
         if (PBK) {
-            const uint32_t kw = live ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
+            const uint32_t kw = kw_next;
             key_phase<L, KEMIT, false>(lds, stage, 0, kw, blk, w, tab, rkr);
             if (KEMIT) {
                 wave_lds_fence();
@@ -425,14 +440,33 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
                 st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkw(10));
             }
             wave_lds_fence();
+            if (R == 1) {
+                AESW_TRACE_POINT(2);
+                // a striding workgroup's next inputs travel while this group is flushed
+                ptw_next = load_word(a.pt, grp + gridDim.x);
+                if (PBK) kw_next = load_word(a.keys, grp + gridDim.x);
+            }
             flush_round<L, NT, R>(lds, stage + St::OX, stage + St::OY, stage + St::OZ, gx, gy, gz, fs, lane);
             wave_lds_fence();
+            if (R == 1) AESW_TRACE_POINT(3);
+            if (R == 5) AESW_TRACE_POINT(4);
+            if (R == 9) AESW_TRACE_POINT(5);
         };
         step(IntC<1>{}); step(IntC<2>{}); step(IntC<3>{}); step(IntC<4>{}); step(IntC<5>{});
         step(IntC<6>{}); step(IntC<7>{}); step(IntC<8>{}); step(IntC<9>{});
 
         if (a.ct && live) reinterpret_cast<uint32_t *>(a.ct)[(blk0 + blk) * 4 + w] = st;
     }
+#ifdef AESW_TRACE
+    if (a.trace) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave acknowledged
+        AESW_TRACE_POINT(6);
+        uint32_t hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (lane0 == 0) a.trace[((uint64_t)(blockIdx.x * waves + wave)) * 8 + 7] = ((uint64_t)xcc << 32) | hwid;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -597,7 +631,7 @@ static hipError_t allow_large_lds(const void *fn, size_t lds) {
 }
 
 template <int L, bool XT, int KM, bool KEMIT, int NT>
-static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool xr, hipStream_t stream) {
+static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool xr, uint32_t lds_pad, hipStream_t stream) {
     const int bpg = waves * BPW;
     const uint64_t groups = (p0.n + bpg - 1) / bpg;
     if (groups == 0) return hipSuccess;
@@ -606,7 +640,7 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
     p.ngroups = (uint32_t)groups;
     p.xcd_remap = xr ? 1u : 0u;
     const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
-    const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KEMIT);
+    const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KEMIT) + lds_pad;
     auto k = encrypt_kernel<L, XT, KM, KEMIT, NT>;
     {
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k), lds);
@@ -617,30 +651,30 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
 }
 
 template <int L, bool XT, int KM, bool KEMIT>
-static hipError_t launch_enc_nt(const EncParams &p, int waves, int nt, uint32_t cap, bool xr, hipStream_t s) {
-    return nt == 3 ? launch_enc<L, XT, KM, KEMIT, 3>(p, waves, cap, xr, s)
-         : nt == 2 ? launch_enc<L, XT, KM, KEMIT, 2>(p, waves, cap, xr, s)
-         : nt == 1 ? launch_enc<L, XT, KM, KEMIT, 1>(p, waves, cap, xr, s)
-                   : launch_enc<L, XT, KM, KEMIT, 0>(p, waves, cap, xr, s);
+static hipError_t launch_enc_nt(const EncParams &p, int waves, int nt, uint32_t cap, bool xr, uint32_t pad, hipStream_t s) {
+    return nt == 3 ? launch_enc<L, XT, KM, KEMIT, 3>(p, waves, cap, xr, pad, s)
+         : nt == 2 ? launch_enc<L, XT, KM, KEMIT, 2>(p, waves, cap, xr, pad, s)
+         : nt == 1 ? launch_enc<L, XT, KM, KEMIT, 1>(p, waves, cap, xr, pad, s)
+                   : launch_enc<L, XT, KM, KEMIT, 0>(p, waves, cap, xr, pad, s);
 }
 
 template <int L, bool XT>
-static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, int nt, uint32_t cap, bool xr, hipStream_t s) {
-    if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, cap, xr, s);
-    if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, cap, xr, s);
-    return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, cap, xr, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, cap, xr, s);
+static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, int nt, uint32_t cap, bool xr, uint32_t pad, hipStream_t s) {
+    if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, cap, xr, pad, s);
+    if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, cap, xr, pad, s);
+    return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, cap, xr, pad, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, cap, xr, pad, s);
 }
 
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, int nt,
-                          uint32_t max_groups_in_flight, bool xcd_remap, hipStream_t s) {
+                          uint32_t max_groups_in_flight, bool xcd_remap, uint32_t pad, hipStream_t s) {
     if (waves < 1 || waves > 4 || keymode < 0 || keymode > 2) return hipErrorInvalidValue;
     const uint32_t cap = max_groups_in_flight;
     const bool xr = xcd_remap && cap == 0;  // the remap assumes one workgroup per group
     if (layout == DENSE)
-        return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, xr, s)
-                  : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, xr, s);
-    return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, cap, xr, s)
-              : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, cap, xr, s);
+        return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, xr, pad, s)
+                  : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, xr, pad, s);
+    return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, cap, xr, pad, s)
+              : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, cap, xr, pad, s);
 }
 
 template <int L, bool XT, int NT>
