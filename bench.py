@@ -46,6 +46,7 @@ def parse():
                     help="c1 = 2^16 blocks shared key (BASELINE configs[1]); c2 = 2^20 blocks per-block keys")
     ap.add_argument("--log2-blocks", type=int, default=None, help="override the batch size (per rank)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--c3-log2-blocks", type=int, default=None, help="N>1 extra: blocks per GPU of the configs[3] run (default 21)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of a hipGraph")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to aesw_set_option")
@@ -124,9 +125,9 @@ class Runner:
                 self.launch(i, sp)
         e1.record()
         torch.cuda.synchronize()
+        t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks is taken by the caller
         if barrier:
             barrier()
-        t1 = time.perf_counter()
         return t1 - t0, e0.elapsed_time(e1) / steps, graph is not None
 
 
@@ -143,7 +144,7 @@ def cpu_baseline(n_target_seconds=12.0):
     t0 = time.perf_counter()
     orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=1)
     rate = probe / (time.perf_counter() - t0)
-    n = int(max(4096, min(1 << 18, rate * n_target_seconds)))
+    n = int(max(4096, min(1 << 20, rate * n_target_seconds)))
     pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
     t0 = time.perf_counter()
     orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=1)
@@ -332,6 +333,45 @@ def main():
             del cells, out
         except Exception as e:
             extras["expand_fr"] = {"error": str(e)}
+        try:  # the key-schedule kernel on its own: 936 B written + 16 B read per key
+            nk = 1 << 20
+            dkeys = torch.randint(0, 256, (nk, 16), dtype=torch.uint8, device="cuda")
+            ctx.key_schedule_witness(dkeys, layout=pkg.LAYOUT_PACKED, want_rk=False)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                kwit = ctx.key_schedule_witness(dkeys, layout=pkg.LAYOUT_PACKED, want_rk=False)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            extras["key_schedule"] = {"keys": nk, "launch_ms": ms, "keys_per_s": nk / (ms * 1e-3),
+                                      "achieved_GBps": 952 * nk / (ms * 1e-3) / 1e9, "frac": 952 * nk / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            del dkeys, kwit
+        except Exception as e:
+            extras["key_schedule"] = {"error": str(e)}
+        try:  # the whole advice matrix of a K=20, N=5 circuit as Fr cells (bulk assignment)
+            k, n_sets = 20, 5
+            nn = pkg.block_capacity(k, n_sets)
+            apt = torch.randint(0, 256, (nn, 16), dtype=torch.uint8, device="cuda")
+            akey = torch.randint(0, 256, (16,), dtype=torch.uint8, device="cuda")
+            kw = ctx.schedule_key(akey, layout=pkg.LAYOUT_PACKED, key_slab=True)
+            wit = ctx.encrypt_witness(apt, None, layout=pkg.LAYOUT_PACKED)
+            adv = ctx.assemble_advice(k, n_sets, wit, kw, nn, layout=pkg.LAYOUT_PACKED, as_fr=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                del adv
+                adv = ctx.assemble_advice(k, n_sets, wit, kw, nn, layout=pkg.LAYOUT_PACKED, as_fr=True)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            extras["assemble_fr"] = {"circuit": "K=20, N=5: 16 advice columns x 2^20 Fr cells, %d blocks" % nn,
+                                     "launch_ms": ms, "written_GBps": adv.numel() / (ms * 1e-3) / 1e9}
+            del adv, wit, apt
+        except Exception as e:
+            extras["assemble_fr"] = {"error": str(e)}
         line["extra"] = extras
     if rank == 0 and world == 1 and not a.no_cpu:
         line["cpu_baseline"] = cpu_baseline()
@@ -344,31 +384,60 @@ def main():
 
         def give_up():
             if rank == 0:
-                line["gather"] = {"error": "timed out after 120 s"}
+                line.setdefault("gather", {"error": "timed out"})
+                line.setdefault("c3", {"error": "timed out"})
                 print(json.dumps(line), flush=True)
             os._exit(0)
 
-        dog = threading.Timer(120.0, give_up)
+        dog = threading.Timer(240.0, give_up)
         dog.daemon = True
         dog.start()
-        try:
-            strides = [pkg.column_stride(layout, c) for c in range(3)]
-            wset = runner.sets[0]
+        strides = [pkg.column_stride(layout, c) for c in range(3)]
+
+        def timed_gather(wset, nblk):
             gcols = [wset.x, wset.y, wset.z] if a.backend == "nccl" else [c.cpu() for c in (wset.x, wset.y, wset.z)]
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            full = pkg.sharding.gather_columns(gcols, [n] * world, strides, dst=0)
+            full = pkg.sharding.gather_columns(gcols, [nblk] * world, strides, dst=0)
             torch.cuda.synchronize()
             dist.barrier()
             dt = time.perf_counter() - t0
+            del full
+            return dt
+
+        try:
+            timed_gather(runner.sets[0], n)  # untimed: connection set-up of the peer-to-peer channels
+            dt = timed_gather(runner.sets[0], n)
             if rank == 0:
                 line["gather"] = {"seconds": dt, "GBps_into_root": (world - 1) * n * sum(strides) / dt / 1e9,
                                   "note": "send/recv of per-rank column ranges to rank 0 (RCCL over xGMI with nccl), outside `value`"}
-            del full
         except Exception as e:
             if rank == 0:
                 line["gather"] = {"error": str(e)}
+        if not a.no_extras:
+            # BASELINE configs[3]: 2^24 blocks over 8 GPUs = 2^21 per GPU, columns gathered on GPU 0 (never `value`)
+            try:
+                del runner
+                torch.cuda.empty_cache()
+                n3 = 1 << (a.c3_log2_blocks or 21)
+                r3 = Runner(pkg, ctx, torch, n3, False, layout, False, SEED + 11 + rank)
+                steps3 = 10
+                w3, ms3, _ = r3.run(steps3, 2, not a.no_graph, barrier)
+                t3 = torch.tensor([w3, ms3], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+                dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+                dt3 = timed_gather(r3.sets[0], n3)
+                if rank == 0:
+                    line["c3"] = {"workload": "2^%d blocks per GPU x %d GPUs, one shared key, %s columns" % (a.c3_log2_blocks or 21, world, a.layout),
+                                  "blocks_total": n3 * world, "blocks_per_s": n3 * world * steps3 / float(t3[0]),
+                                  "launch_ms": float(t3[1]),
+                                  "achieved_GBps_per_gpu": BYTES_SHARED * n3 / (float(t3[1]) * 1e-3) / 1e9,
+                                  "gather_seconds": dt3, "gather_GBps_into_root": (world - 1) * n3 * sum(strides) / dt3 / 1e9,
+                                  "note": "generation and gather timed separately; the gather is bound by the root's xGMI ingest"}
+                del r3
+            except Exception as e:
+                if rank == 0:
+                    line["c3"] = {"error": str(e)}
         dog.cancel()
         try:
             dist.barrier()

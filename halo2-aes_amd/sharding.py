@@ -26,14 +26,17 @@ def shard_sizes(n: int, world: int) -> List[int]:
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[int], dst: int = 0, group=None):
+def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[int], dst: int = 0, group=None,
+                   max_message_bytes: int = 1 << 30):
     """Gather per-rank column slices on rank `dst`.
 
     columns: this rank's column tensors (uint8, flat, counts[rank]*stride bytes).
     counts:  blocks per rank (len == world).  strides: bytes per block per column.
     Returns the full columns on `dst` (list of tensors), None elsewhere.
     Uses send/recv pairs so ragged shard sizes need no padding; with the nccl
-    backend every peer->root transfer rides its own xGMI link.
+    backend every peer->root transfer rides its own xGMI link.  A rank's range of
+    one column travels as messages of at most `max_message_bytes` (BASELINE
+    configs[3] moves 2.9 GB per column and rank).
     """
     import torch
     import torch.distributed as dist
@@ -42,6 +45,8 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
     world = dist.get_world_size(group)
     if len(counts) != world or len(columns) != len(strides):
         raise ValueError("counts/strides do not match world size / columns")
+    if max_message_bytes <= 0:
+        raise ValueError("max_message_bytes must be positive")
     total = sum(counts)
     offs = [sum(counts[:r]) for r in range(world)]
     # One grouped batch of point-to-point operations: with the nccl backend (RCCL) the group is
@@ -57,10 +62,13 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
                 if r == dst:
                     view.copy_(col[:counts[r] * s])
                 elif counts[r]:
-                    ops.append(dist.P2POp(dist.irecv, view, r, group))
+                    for o in range(0, view.numel(), max_message_bytes):
+                        ops.append(dist.P2POp(dist.irecv, view[o:o + max_message_bytes], r, group))
     elif counts[rank]:
         for col, s in zip(columns, strides):
-            ops.append(dist.P2POp(dist.isend, col[:counts[rank] * s].contiguous(), dst, group))
+            mine = col[:counts[rank] * s].contiguous()
+            for o in range(0, mine.numel(), max_message_bytes):
+                ops.append(dist.P2POp(dist.isend, mine[o:o + max_message_bytes], dst, group))
     if ops:
         for q in dist.batch_isend_irecv(ops):
             q.wait()

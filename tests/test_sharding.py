@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, layout, tmp):
+def _worker(rank, world, port, n, layout, tmp, max_msg):
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
@@ -53,7 +53,7 @@ def _worker(rank, world, port, n, layout, tmp):
         w = ol.Oracle().encrypt_witness(pt[lo:hi], key, layout=layout) if hi > lo else None
         strides = [pkg.column_stride(layout, c) for c in range(3)]
         cols = [torch.from_numpy(getattr(w, c)) if w is not None else torch.empty(0, dtype=torch.uint8) for c in "xyz"]
-        full = pkg.sharding.gather_columns(cols, pkg.sharding.shard_sizes(n, world), strides, dst=0)
+        full = pkg.sharding.gather_columns(cols, pkg.sharding.shard_sizes(n, world), strides, dst=0, max_message_bytes=max_msg)
         if rank == 0:
             exp = ol.Oracle().encrypt_witness(pt, key, layout=layout)
             ok = all(np.array_equal(f.numpy(), getattr(exp, c)) for f, c in zip(full, "xyz"))
@@ -65,9 +65,9 @@ def _worker(rank, world, port, n, layout, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 37), (3, 5), (2, 1)])
-def test_gather_columns_gloo(pkg, tmp_path, world, n):
+@pytest.mark.parametrize("world,n,max_msg", [(2, 37, 1 << 30), (3, 5, 1 << 30), (2, 1, 1 << 30), (2, 37, 1000)])
+def test_gather_columns_gloo(pkg, tmp_path, world, n, max_msg):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, n, pkg.LAYOUT_PACKED, tmp_path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n, pkg.LAYOUT_PACKED, tmp_path, max_msg), nprocs=world, join=True)
     assert (tmp_path / "result").read_text() == "ok"
