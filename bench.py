@@ -292,6 +292,17 @@ def main():
             dt = time.perf_counter() - t0
             res["stream"] = {"blocks": nn2, "blocks_per_s": nn2 / dt, "GBps_to_host": nn2 * 3024 / dt / 1e9,
                              "chunks_seen_blocks": seen[0]}
+            # the link itself: one page-locked 1 GiB device-to-host copy, for scale
+            dsrc = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+            hdst = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
+            hdst.copy_(dsrc, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hdst.copy_(dsrc, non_blocking=True)
+            torch.cuda.synchronize()
+            res["raw_d2h_GBps"] = 3 * (1 << 30) / (time.perf_counter() - t0) / 1e9
+            del dsrc, hdst
             extras["pcie_inclusive"] = res
         except Exception as e:
             extras["pcie_inclusive"] = {"error": str(e)}
