@@ -260,38 +260,45 @@ def main():
                 extras[name] = {"error": str(e)}
         try:  # PCIe-inclusive rate of the host-pointer entry point (never `value`)
             import numpy as np
-            nn = 1 << 18
-            hpt = np.random.default_rng(SEED).integers(0, 256, (nn, 16), dtype=np.uint8)
-            res = {"blocks": nn, "note": "aesw_encrypt_witness: H2D + kernels + overlapped D2H, packed layout"}
+            nn = 1 << 20
+            hpt = pkg.api.host_alloc(nn * 16).reshape(nn, 16)   # page-locked input, like the outputs
+            hpt[:] = np.random.default_rng(SEED).integers(0, 256, (nn, 16), dtype=np.uint8)
+            res = {"blocks": nn, "note": "aesw_encrypt_witness: H2D + kernels + overlapped D2H, packed layout, 2^15-block chunks"}
             for kind in ("pinned", "pageable"):
                 if kind == "pinned":
                     outs = [pkg.api.host_alloc(nn * pkg.column_stride(pkg.LAYOUT_PACKED, c)) for c in range(3)]
                 else:
                     outs = [np.empty(nn * pkg.column_stride(pkg.LAYOUT_PACKED, c), np.uint8) for c in range(3)]
-                ctx.encrypt_witness_host(hpt[:4096], None, layout=pkg.LAYOUT_PACKED, out_cols=outs)  # warm-up
-                t0 = time.perf_counter()
-                ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_PACKED, out_cols=outs)
-                dt = time.perf_counter() - t0
+                ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_PACKED, out_cols=outs)  # sizes the context's buffers
+                dts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_PACKED, out_cols=outs)
+                    dts.append(time.perf_counter() - t0)
+                dt = sorted(dts)[1]  # median of three calls
                 res[kind] = {"blocks_per_s": nn / dt, "GBps_to_host": nn * 3024 / dt / 1e9}
                 if kind == "pinned":
                     for o in outs:
                         pkg.api.host_free(o)
+                del outs
             # streaming form: a consumer callback per 2^15-block chunk while the next chunk is in flight
-            nn2 = 1 << 20
-            hpt2 = np.random.default_rng(SEED + 5).integers(0, 256, (nn2, 16), dtype=np.uint8)
             seen = [0]
 
             def consume(first, count, x, y, z):
-                seen[0] += int(x[::4096].sum() & 0) + count   # touch the chunk, keep it cheap
+                seen[0] += count
                 return 0
 
-            ctx.encrypt_witness_stream(hpt2[:65536], None, consume, layout=pkg.LAYOUT_PACKED)
-            seen[0] = 0
-            t0 = time.perf_counter()
-            ctx.encrypt_witness_stream(hpt2, None, consume, layout=pkg.LAYOUT_PACKED)
-            dt = time.perf_counter() - t0
-            res["stream"] = {"blocks": nn2, "blocks_per_s": nn2 / dt, "GBps_to_host": nn2 * 3024 / dt / 1e9,
+            ctx.encrypt_witness_stream(hpt, None, consume, layout=pkg.LAYOUT_PACKED)
+            dts = []
+            for _ in range(3):
+                seen[0] = 0
+                t0 = time.perf_counter()
+                ctx.encrypt_witness_stream(hpt, None, consume, layout=pkg.LAYOUT_PACKED)
+                dts.append(time.perf_counter() - t0)
+            dt = sorted(dts)[1]
+            res["stream"] = {"blocks": nn, "blocks_per_s": nn / dt, "GBps_to_host": nn * 3024 / dt / 1e9,
                              "chunks_seen_blocks": seen[0]}
+            pkg.api.host_free(hpt)
             # the link itself: one page-locked 1 GiB device-to-host copy, for scale
             dsrc = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
             hdst = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()

@@ -367,7 +367,9 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
 // Waves per group when the option is 0 (auto): as many 16-block waves as keep
 // 6-8 waves resident per CU given the LDS windows (DESIGN.md "occupancy").
 static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
-    if (pbk) return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_PACKED ? 2 : 1);
+    // per-block keys: 3-wave groups (2 per CU) measured 3-4 % ahead of 2- and 1-wave groups at 2^20 blocks on two
+    // boxes (tools/sweep.py 20 c2 packed waves); dense: 1..3 equal, 4 slower
+    if (pbk) return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_PACKED ? 3 : 1);
     if (ctx->waves_shared) return ctx->waves_shared;
     return 4;  // 64 blocks per group: line-aligned in every column, fewest table loads
 }

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "aesw_internal.h"
 #include "aesw_lane.h"
 
@@ -621,6 +623,8 @@ static hipError_t allow_large_lds(const void *fn, size_t lds) {
     struct Seen { const void *fn; int dev; size_t lds; };
     static Seen seen[256];
     static int n_seen = 0;
+    static std::mutex mu;  // contexts on different host threads launch concurrently
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
     for (int i = 0; i < n_seen; ++i)

@@ -23,6 +23,9 @@ if len(sys.argv) > 4 and sys.argv[4] == "cap":
     for w in (4, 3, 2):
         for cap in (0, 256 * (8 // w), 256 * (8 // w) * 3 // 2, 256 * (8 // w) // 2):
             variants.append({"waves_shared": w, "waves_pbk": w, "grid_cap": cap})
+elif len(sys.argv) > 4 and sys.argv[4] == "waves":
+    for w in (4, 3, 2, 1):
+        variants.append({"waves_shared": w, "waves_pbk": w})
 elif len(sys.argv) > 4 and sys.argv[4] == "cap4":
     for cap in (0, 128, 192, 224, 256, 288, 320, 384, 512):
         variants.append({"waves_shared": 4, "waves_pbk": 4, "grid_cap": cap})
