@@ -374,6 +374,11 @@ static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
     return 4;  // 64 blocks per group: line-aligned in every column, fewest table loads
 }
 
+// key_kernel alone (tools/keysweep.py, 2^20 keys): packed 4-wave groups, dense 2-wave groups
+static int auto_waves_key(const aesw_ctx *ctx, int layout) {
+    return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_PACKED ? 4 : 2);
+}
+
 int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, const aesw_key_slab *ks, void *stream) {
     if (!ctx || !valid_layout(layout) || !d_key || !aligned4(d_key)) return AESW_ERR_INVALID_ARG;
     KeyOut ko{nullptr, nullptr, nullptr, nullptr};
@@ -443,7 +448,7 @@ int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint6
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     KeyParams kp{d_keys, ctx->d_tables, KeyOut{d_w, d_kx, d_ky, d_kz}, d_rk, n};
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves(ctx, layout, true), ctx->nt, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves_key(ctx, layout), ctx->nt, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 
