@@ -33,6 +33,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 BYTES_SHARED = 3040     # 3024 live cells written + 16 B plaintext read per block
 BYTES_PBK = 3992        # + 936 key-schedule cells + 16 B key read per block
+BYTES_VALUES = 1072     # AESW_LAYOUT_VALUES: 448 + 608 closure-computed cells written + 16 B read per block
 SEED = 0xA35128
 
 
@@ -41,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--layout", choices=["packed", "dense"], default="packed")
+    ap.add_argument("--layout", choices=["packed", "dense", "values"], default="packed")
     ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
                     help="c1 = 2^16 blocks shared key (BASELINE configs[1]); c2 = 2^20 blocks per-block keys")
     ap.add_argument("--log2-blocks", type=int, default=None, help="override the batch size (per rank)")
@@ -78,6 +79,8 @@ class Runner:
         self.h = ctx._h
         self._ks = [pkg.api.KeySlab(*[t.data_ptr() for t in s.key[:4]]) if key_slab else None for s in self.sets]
         self.bytes_per_block = BYTES_PBK if (per_block_keys and key_slab) else BYTES_SHARED
+        if layout == pkg.LAYOUT_VALUES:  # only closure-computed cells: 448 + 608 B written, 16 B read per block
+            self.bytes_per_block = BYTES_VALUES + (936 + 16 if (per_block_keys and key_slab) else 0)
 
     def launch(self, i, stream):
         s = self.sets[i % self.nsets]
@@ -189,7 +192,7 @@ def main():
     for opt in a.option:
         k, v = opt.split("=")
         ctx.set_option(k, int(v))
-    layout = pkg.LAYOUT_PACKED if a.layout == "packed" else pkg.LAYOUT_DENSE
+    layout = {"packed": pkg.LAYOUT_PACKED, "dense": pkg.LAYOUT_DENSE, "values": pkg.LAYOUT_VALUES}[a.layout]
     host_bufs = None
     if rank == 0 and world == 1 and not a.no_extras:
         # Page-locked buffers of the PCIe-inclusive extra are taken first, as a host would at start-up.
@@ -293,6 +296,17 @@ def main():
             dt = sorted(dts)[1]
             res["stream"] = {"blocks": nn, "blocks_per_s": nn / dt, "GBps_to_host": nn * 3024 / dt / 1e9,
                              "chunks_seen_blocks": seen[0]}
+            # the closure-computed cells only (AESW_LAYOUT_VALUES, 1 056 B per block): what a host that keeps
+            # the chips' copy_advice() calls has to receive
+            vouts = [np.empty(0, np.uint8), pinned_outs[1][:nn * 448], pinned_outs[2][:nn * 608]]
+            ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_VALUES, out_cols=vouts)
+            dts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_VALUES, out_cols=vouts)
+                dts.append(time.perf_counter() - t0)
+            dt = sorted(dts)[1]
+            res["pinned_values_layout"] = {"blocks_per_s": nn / dt, "GBps_to_host": nn * 1056 / dt / 1e9}
             pkg.api.host_free(hpt)
             for o in pinned_outs:
                 pkg.api.host_free(o)
@@ -314,7 +328,9 @@ def main():
         for name, nn, pbk, lay in (("c1_dense", 1 << 16, False, pkg.LAYOUT_DENSE),
                                    ("c1_packed_2p20", 1 << 20, False, pkg.LAYOUT_PACKED),
                                    ("c2_packed", 1 << 20, True, pkg.LAYOUT_PACKED),
-                                   ("c2_dense", 1 << 20, True, pkg.LAYOUT_DENSE)):
+                                   ("c2_dense", 1 << 20, True, pkg.LAYOUT_DENSE),
+                                   ("c1_values", 1 << 16, False, pkg.LAYOUT_VALUES),
+                                   ("c1_values_2p20", 1 << 20, False, pkg.LAYOUT_VALUES)):
             try:
                 r = Runner(pkg, ctx, torch, nn, pbk, lay, pbk, SEED + 7)
                 steps = 50 if nn <= (1 << 16) else 12

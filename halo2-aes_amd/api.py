@@ -52,6 +52,7 @@ SYMBOLS = {
     "aesw_column_stride": (_U32, [_I, _I]),
     "aesw_key_column_stride": (_U32, [_I, _I]),
     "aesw_packed_index": (_I, [_I, _P]),
+    "aesw_layout_index": (_I, [_I, _I, _P]),
     "aesw_key_packed_index": (_I, [_I, _P]),
     "aesw_block_placement": (_I, [_U32, _U32, _U64, C.POINTER(_U32), C.POINTER(_U64)]),
     "aesw_block_capacity": (_U64, [_U32, _U32]),
@@ -153,6 +154,15 @@ def key_column_stride(layout: int, col: int) -> int:
 def packed_index(col: int) -> np.ndarray:
     idx = np.zeros(K.AES_ROWS, dtype=np.int32)
     rc = load_library().aesw_packed_index(col, _np_ptr(idx))
+    if rc:
+        raise AeswError(rc)
+    return idx
+
+
+def layout_index(layout: int, col: int) -> np.ndarray:
+    """dense row -> index in column `col` of `layout` (-1: the layout leaves the cell out)."""
+    idx = np.zeros(K.AES_ROWS, dtype=np.int32)
+    rc = load_library().aesw_layout_index(layout, col, _np_ptr(idx))
     if rc:
         raise AeswError(rc)
     return idx
@@ -372,7 +382,8 @@ class Context:
         if out.key is not None:
             ks = KeySlab(*[t.data_ptr() if t is not None else None for t in out.key[:4]])
         rc = self._lib.aesw_encrypt_witness_device(
-            self._h, pt.data_ptr(), keys.data_ptr() if keys is not None else None, pbk, n, layout, out.x.data_ptr(), out.y.data_ptr(),
+            self._h, pt.data_ptr(), keys.data_ptr() if keys is not None else None, pbk, n, layout,
+            out.x.data_ptr() if out.x.numel() else None, out.y.data_ptr(),
             out.z.data_ptr(), out.ct.data_ptr() if out.ct is not None else None,
             C.byref(ks) if ks is not None else None, self._stream())
         self._check(rc, "aesw_encrypt_witness_device")
@@ -476,7 +487,8 @@ class Context:
         @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8))
         def cb(_user, first, count, x, y, z):
             try:
-                cols = [np.ctypeslib.as_array(p, shape=(count * s,)) for p, s in zip((x, y, z), strides)]
+                cols = [np.ctypeslib.as_array(p, shape=(count * s,)) if s else np.empty(0, np.uint8)  # VALUES: no x
+                        for p, s in zip((x, y, z), strides)]
                 r = consume(int(first), int(count), *cols)
                 return int(r or 0)
             except Exception as e:  # never let an exception cross the C boundary

@@ -22,6 +22,7 @@ ROUND_CONSTANT = (1, 2, 4, 8, 16, 32, 64, 128, 27, 54)  # src/utils.rs:28
 
 LAYOUT_DENSE = 0
 LAYOUT_PACKED = 1
+LAYOUT_VALUES = 2   # only closure-computed cells: y of S-box/mul rows (448 B/block), z of xor rows (608 B/block)
 
 
 def _xtime(a: int) -> int:

@@ -73,7 +73,7 @@ struct DeviceGuard {
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
-bool valid_layout(int l) { return l == AESW_LAYOUT_DENSE || l == AESW_LAYOUT_PACKED; }
+bool valid_layout(int l) { return l == AESW_LAYOUT_DENSE || l == AESW_LAYOUT_PACKED || l == AESW_LAYOUT_VALUES; }
 
 uint8_t xtime(uint8_t a) { return (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0)); }
 
@@ -225,6 +225,7 @@ int aesw_uses_xtime_path(const aesw_ctx *ctx) { return ctx && ctx->xt ? 1 : 0; }
 uint32_t aesw_column_stride(int layout, int col) {
     if (!valid_layout(layout) || col < 0 || col > 2) return 0;
     if (layout == AESW_LAYOUT_DENSE) return AESW_AES_ROWS;
+    if (layout == AESW_LAYOUT_VALUES) return col == 0 ? Geo<VALUES>::XS : col == 1 ? Geo<VALUES>::YS : Geo<VALUES>::ZS;
     return col == 0 ? Geo<PACKED>::XS : col == 1 ? Geo<PACKED>::YS : Geo<PACKED>::ZS;
 }
 
@@ -238,6 +239,20 @@ int aesw_packed_index(int col, int32_t idx[AESW_AES_ROWS]) {
     if (col < 0 || col > 2 || !idx) return AESW_ERR_INVALID_ARG;
     uint8_t mask[AES_ROWS];
     encrypt_assigned_mask(col, mask);
+    int32_t n = 0;
+    for (int r = 0; r < AES_ROWS; ++r) idx[r] = mask[r] ? n++ : -1;
+    return AESW_OK;
+}
+
+int aesw_layout_index(int layout, int col, int32_t idx[AESW_AES_ROWS]) {
+    if (!valid_layout(layout) || col < 0 || col > 2 || !idx) return AESW_ERR_INVALID_ARG;
+    if (layout == AESW_LAYOUT_DENSE) {
+        for (int r = 0; r < AES_ROWS; ++r) idx[r] = r;
+        return AESW_OK;
+    }
+    if (layout == AESW_LAYOUT_PACKED) return aesw_packed_index(col, idx);
+    uint8_t mask[AES_ROWS];
+    encrypt_values_mask(col, mask);
     int32_t n = 0;
     for (int r = 0; r < AES_ROWS; ++r) idx[r] = mask[r] ? n++ : -1;
     return AESW_OK;
@@ -369,14 +384,14 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
 static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
     // per-block keys: 3-wave groups (2 per CU) measured 3-4 % ahead of 2- and 1-wave groups at 2^20 blocks on two
     // boxes (tools/sweep.py 20 c2 packed waves); dense: 1..3 equal, 4 slower
-    if (pbk) return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_PACKED ? 3 : 1);
+    if (pbk) return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_DENSE ? 1 : 3);
     if (ctx->waves_shared) return ctx->waves_shared;
     return 4;  // 64 blocks per group: line-aligned in every column, fewest table loads
 }
 
 // key_kernel alone (tools/keysweep.py, 2^20 keys): packed 4-wave groups, dense 2-wave groups
 static int auto_waves_key(const aesw_ctx *ctx, int layout) {
-    return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_PACKED ? 4 : 2);
+    return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_DENSE ? 2 : 4);
 }
 
 int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, const aesw_key_slab *ks, void *stream) {
@@ -405,8 +420,9 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
         if (!ctx->have_key) return AESW_ERR_NO_KEY;  // "Keys should be scheduled", src/aes128.rs:170
     }
     if (n == 0) return AESW_OK;
-    if (!d_pt || !d_x || !d_y || !d_z) return AESW_ERR_INVALID_ARG;
-    if (!aligned16(d_x) || !aligned16(d_y) || !aligned16(d_z) || !aligned4(d_pt) || (d_keys && !aligned4(d_keys)) ||
+    const bool has_x = aesw_column_stride(layout, 0) != 0;  // AESW_LAYOUT_VALUES has no x column: d_x is ignored
+    if (!d_pt || (has_x && !d_x) || !d_y || !d_z) return AESW_ERR_INVALID_ARG;
+    if ((has_x && !aligned16(d_x)) || !aligned16(d_y) || !aligned16(d_z) || !aligned4(d_pt) || (d_keys && !aligned4(d_keys)) ||
         (d_ct && !aligned4(d_ct)))
         return AESW_ERR_INVALID_ARG;
     KeyOut ko{nullptr, nullptr, nullptr, nullptr};
@@ -463,7 +479,8 @@ int aesw_lookup_table_device(aesw_ctx *ctx, uint8_t *d_t0, uint8_t *d_t1, uint8_
 int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks, int layout, const uint8_t *d_x,
                                 const uint8_t *d_y, const uint8_t *d_z, const aesw_key_slab *ks, int as_fr, uint8_t *d_out,
                                 void *stream) {
-    if (!ctx || !valid_layout(layout) || k < 2 || k > 32 || n_sets == 0 || n_sets > 1024 || !d_out || !aligned16(d_out))
+    if (!ctx || !valid_layout(layout) || layout == AESW_LAYOUT_VALUES /* whole columns need every cell */ || k < 2 || k > 32 ||
+        n_sets == 0 || n_sets > 1024 || !d_out || !aligned16(d_out))
         return AESW_ERR_INVALID_ARG;
     if (n_blocks && (!d_x || !d_y || !d_z)) return AESW_ERR_INVALID_ARG;
     if (n_blocks > aesw_block_capacity(k, n_sets)) return AESW_ERR_CAPACITY;  // panic in the reference, src/aes128.rs:160-162
@@ -559,7 +576,7 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
                          int layout, uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct, const aesw_key_slab *ks) {
     if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;
     if (n == 0) return AESW_OK;
-    if (!pt || !x || !y || !z) return AESW_ERR_INVALID_ARG;
+    if (!pt) return AESW_ERR_INVALID_ARG;  // x / y / z: a null column is computed but not copied back
     if (!keys && (per_block_keys || (ks && (ks->w || ks->kx || ks->ky || ks->kz)))) return AESW_ERR_INVALID_ARG;
     if (!keys && !ctx->have_key) return AESW_ERR_NO_KEY;
     DeviceGuard g(ctx->device);
@@ -599,7 +616,7 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         }
     }
     HostCol cols[7] = {
-        {x, {dx[0].p, dx[1].p}, sx, false, 0}, {y, {dy[0].p, dy[1].p}, sy, false, 0}, {z, {dz[0].p, dz[1].p}, sz, false, 0},
+        {sx ? x : nullptr, {dx[0].p, dx[1].p}, sx, false, 0}, {y, {dy[0].p, dy[1].p}, sy, false, 0}, {z, {dz[0].p, dz[1].p}, sz, false, 0},
         {pbk && kemit ? ks->w : nullptr, {dw[0].p, dw[1].p}, WORDS_ROWS, false, 0},
         {pbk && kemit ? ks->kx : nullptr, {dkx[0].p, dkx[1].p}, kxs, false, 0},
         {pbk && kemit ? ks->ky : nullptr, {dky[0].p, dky[1].p}, kys, false, 0},
@@ -749,7 +766,8 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
         HIP_TRY(ctx, hipEventRecord(done[s], ctx->s_compute));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
         for (int c = 0; c < 3; ++c)
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[s] + boff[c], d + col_off[s][c], m * strides[c], hipMemcpyDeviceToHost, ctx->s_copy));
+            if (strides[c])
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[s] + boff[c], d + col_off[s][c], m * strides[c], hipMemcpyDeviceToHost, ctx->s_copy));
         HIP_TRY(ctx, hipEventRecord(copied[s], ctx->s_copy));
         first[s] = b0; count[s] = m; busy[s] = true;
         return AESW_OK;
@@ -767,7 +785,8 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
         if (!busy[s]) break;
         HIP_TRY(ctx, hipEventSynchronize(copied[s]));
         busy[s] = false;
-        if (consume(user, first[s], count[s], ctx->bounce[s] + boff[0], ctx->bounce[s] + boff[1], ctx->bounce[s] + boff[2]) != 0)
+        if (consume(user, first[s], count[s], strides[0] ? ctx->bounce[s] + boff[0] : nullptr /* AESW_LAYOUT_VALUES: no x */,
+                    ctx->bounce[s] + boff[1], ctx->bounce[s] + boff[2]) != 0)
             return AESW_ERR_MISMATCH;
         if (b0 < n) {
             const uint64_t m = n - b0 < chunk ? n - b0 : chunk;

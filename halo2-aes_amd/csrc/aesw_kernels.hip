@@ -186,10 +186,10 @@ __device__ __forceinline__ void flush_round(const uint8_t *lds, uint32_t sx, uin
     FlushBatch<WinX<L>> bx;
     FlushBatch<WinY<L>> by;
     FlushBatch<WinZ<L>> bz;
-    bx.template load<R>(lds, sx, fs.x, lane);
+    if (Geo<L>::HAS_X) bx.template load<R>(lds, sx, fs.x, lane);
     by.template load<R>(lds, sy, fs.y, lane);
     bz.template load<R>(lds, sz, fs.z, lane);
-    bx.template store<R, NT>(gx);
+    if (Geo<L>::HAS_X) bx.template store<R, NT>(gx);
     by.template store<R, NT>(gy);
     bz.template store<R, NT>(gz);
 }
@@ -219,7 +219,7 @@ struct Stage {
     using WX = WinX<L>;
     using WY = WinY<L>;
     using WZ = WinZ<L>;
-    static constexpr int SX = WX::BYTES, SY = WY::BYTES, SZ = WZ::BYTES;  // window bytes per block
+    static constexpr int SX = Geo<L>::HAS_X ? WX::BYTES : 0, SY = WY::BYTES, SZ = WZ::BYTES;  // window bytes per block
     static constexpr int OX = 0, OY = BPW * SX, OZ = OY + BPW * SY;
     static constexpr int ENC_BYTES = OZ + BPW * SZ;
     using G = Geo<L>;
@@ -677,6 +677,9 @@ hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, 
     if (layout == DENSE)
         return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, xr, pad, s)
                   : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, xr, pad, s);
+    if (layout == VALUES)
+        return xt ? launch_enc_mode<VALUES, true>(p, keymode, kemit, waves, nt, cap, xr, pad, s)
+                  : launch_enc_mode<VALUES, false>(p, keymode, kemit, waves, nt, cap, xr, pad, s);
     return xt ? launch_enc_mode<PACKED, true>(p, keymode, kemit, waves, nt, cap, xr, pad, s)
               : launch_enc_mode<PACKED, false>(p, keymode, kemit, waves, nt, cap, xr, pad, s);
 }

@@ -84,13 +84,15 @@ AESW_HD uint32_t shift_rows(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3) 
 template <int L, class S>
 AESW_HD uint32_t emit_head(S &s, uint32_t ptw, uint32_t rk0w) {
     using G = Geo<L>;
-    s.template plain<0>(G::X_H_PT, ptw);
-    s.template plain<0>(G::X_H_ARK, ptw);
+    if (G::HAS_X) {
+        s.template plain<0>(G::X_H_PT, ptw);
+        s.template plain<0>(G::X_H_ARK, ptw);
+    }
     if (L == DENSE) {
         s.template plain<1>(0, 0u);
         s.template plain<2>(0, 0u);
     }
-    s.template plain<1>(G::Y_H_ARK, rk0w);
+    if (G::Y_COPIES) s.template plain<1>(G::Y_H_ARK, rk0w);
     const uint32_t st = ptw ^ rk0w;
     s.template plain<2>(G::Z_H_ARK, st);
     return st;
@@ -101,7 +103,7 @@ AESW_HD uint32_t emit_head(S &s, uint32_t ptw, uint32_t rk0w) {
 template <int L, class S, class T>
 AESW_HD uint32_t emit_sbox(S &s, int relx, int rely, int relz, uint32_t st, const T &tab) {
     using G = Geo<L>;
-    s.template plain<0>(relx + G::X_SBOX, st);
+    if (G::HAS_X) s.template plain<0>(relx + G::X_SBOX, st);
     const uint32_t sub = tab.sbox4(st);
     s.template plain<1>(rely + G::Y_SBOX, sub);
     if (L == DENSE) s.template plain<2>(relz + G::Z_SBOX, 0u);
@@ -134,7 +136,7 @@ AESW_HD uint32_t emit_mix_ark(S &s, int relx, int rely, int relz, uint32_t sh, u
     const uint32_t MX = I1 ^ I2;
 
     // x: per m the 7 bytes [sh0 sh1 sh2 sh3 T0.m T2.m I1.m]
-    {
+    if (G::HAS_X) {
         const int o = relx + G::X_MIX;
         s.template mix<0>(o, 0, sh);
         uint32_t u = perm(T2, T0, SEL(0, 4, X_, X_));
@@ -164,6 +166,10 @@ AESW_HD uint32_t emit_mix_ark(S &s, int relx, int rely, int relz, uint32_t sh, u
             s.template mix<1>(o, 5, perm(T0, I2, SEL(2, 7, Z_, Z_)));
             u = perm(T3, T1, SEL(7, 3, 7, X_));
             s.template mix<1>(o, 6, perm(I2, u, SEL(0, 1, 2, 7)));
+        } else if (L == VALUES) {
+            // per m: the two products in t order: m0 [2a0 3a1]  m1 [2a1 3a2]  m2 [2a2 3a3]  m3 [3a0 2a3]
+            s.template mix<1>(o, 0, perm(m3, m2, SEL(0, 5, 1, 6)));
+            s.template mix<1>(o, 1, perm(m3, m2, SEL(2, 7, 4, 3)));
         } else {
             // per m: the two products in t order, then T1.m, T3.m, I2.m
             uint32_t u = perm(T1, T0, SEL(0, 4, 4, X_));
@@ -204,8 +210,8 @@ AESW_HD uint32_t emit_mix_ark(S &s, int relx, int rely, int relz, uint32_t sh, u
         }
     }
     // AddRoundKey rows
-    s.template plain<0>(relx + G::X_ARK, MX);
-    s.template plain<1>(rely + G::Y_ARK, rkw);
+    if (G::HAS_X) s.template plain<0>(relx + G::X_ARK, MX);
+    if (G::Y_COPIES) s.template plain<1>(rely + G::Y_ARK, rkw);
     const uint32_t nx = MX ^ rkw;
     s.template plain<2>(relz + G::Z_ARK, nx);
     return nx;
@@ -216,8 +222,8 @@ AESW_HD uint32_t emit_mix_ark(S &s, int relx, int rely, int relz, uint32_t sh, u
 template <int L, class S>
 AESW_HD uint32_t emit_final_ark(S &s, int relx, int rely, int relz, uint32_t sh, uint32_t rkw) {
     using G = Geo<L>;
-    s.template plain<0>(relx + G::X_T_ARK, sh);
-    s.template plain<1>(rely + G::Y_T_ARK, rkw);
+    if (G::HAS_X) s.template plain<0>(relx + G::X_T_ARK, sh);
+    if (G::Y_COPIES) s.template plain<1>(rely + G::Y_T_ARK, rkw);
     const uint32_t ct = sh ^ rkw;
     s.template plain<2>(relz + G::Z_T_ARK, ct);
     return ct;

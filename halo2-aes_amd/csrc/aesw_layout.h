@@ -16,7 +16,10 @@
 
 namespace aesw {
 
-enum : int { DENSE = 0, PACKED = 1 };
+// DENSE: exact image of the advice rows.  PACKED: assigned cells only, row order.  VALUES: only the cells
+// whose value a chip's closure computes -- y of the S-box and mul rows, z of the xor rows; column x and the
+// y cells of xor rows are copy_advice() of earlier cells in the reference (src/chips/*.rs) and are omitted.
+enum : int { DENSE = 0, PACKED = 1, VALUES = 2 };
 
 constexpr int AES_ROWS = 1360;  // src/constant.rs:114
 constexpr int KEY_ROWS = 400;   // 10 rounds x 40 one-row chip regions (src/key_schedule.rs:122-224)
@@ -30,13 +33,16 @@ constexpr int RK_BYTES = 176;   // 11 round keys
 // MIXW/4... bytes per lane-word, ARK rows.
 template <int L>
 struct Geo {
+    static constexpr bool HAS_X = L != VALUES;      // column x is emitted at all
+    static constexpr bool Y_COPIES = L != VALUES;   // y cells of xor rows (round keys, tmp1/tmp3/i2) are emitted
     // bytes per block
-    static constexpr int XS = 1360;
-    static constexpr int YS = L == DENSE ? 1360 : 1056;
+    static constexpr int XS = HAS_X ? 1360 : 0;
+    static constexpr int YS = L == DENSE ? 1360 : L == PACKED ? 1056 : 448;
     static constexpr int ZS = L == DENSE ? 1360 : 608;
     // head / round / tail bytes
     static constexpr int X_HEAD = 32, X_ROUND = 144, X_TAIL = 32;
-    static constexpr int Y_HEAD = L == DENSE ? 32 : 16, Y_ROUND = L == DENSE ? 144 : 112, Y_TAIL = 32;
+    static constexpr int Y_HEAD = L == DENSE ? 32 : L == PACKED ? 16 : 0, Y_ROUND = L == DENSE ? 144 : L == PACKED ? 112 : 48,
+                         Y_TAIL = L == VALUES ? 16 : 32;
     static constexpr int Z_HEAD = L == DENSE ? 32 : 16, Z_ROUND = L == DENSE ? 144 : 64,
                          Z_TAIL = L == DENSE ? 32 : 16;
     // offsets inside the head (relative to the head start)
@@ -45,17 +51,19 @@ struct Geo {
     static constexpr int Z_H_ARK = L == DENSE ? 16 : 0;   // pt ^ rk0
     // offsets inside a round (relative to the round start)
     static constexpr int X_SBOX = 0, X_MIX = 16, X_MIXW = 28, X_ARK = 128;
-    static constexpr int Y_SBOX = 0, Y_MIX = 16, Y_MIXW = L == DENSE ? 28 : 20, Y_ARK = L == DENSE ? 128 : 96;
+    static constexpr int Y_SBOX = 0, Y_MIX = 16, Y_MIXW = L == DENSE ? 28 : L == PACKED ? 20 : 8,
+                         Y_ARK = L == DENSE ? 128 : 96 /* not in VALUES */;
     static constexpr int Z_SBOX = 0 /* dense only: zeros */, Z_MIX = L == DENSE ? 16 : 0,
                          Z_MIXW = L == DENSE ? 28 : 12, Z_ARK = L == DENSE ? 128 : 48;
     // offsets inside the tail (round 10: sbox rows, then ShiftRows ^ rk10)
     static constexpr int X_T_SBOX = 0, X_T_ARK = 16;
-    static constexpr int Y_T_SBOX = 0, Y_T_ARK = 16;
+    static constexpr int Y_T_SBOX = 0, Y_T_ARK = 16 /* not in VALUES */;
     static constexpr int Z_T_ARK = L == DENSE ? 16 : 0;
     // dwords per lcon record group of one lane-word (4 output bytes x 7 rows)
-    static constexpr int X_MIXD = 7, Y_MIXD = L == DENSE ? 7 : 5, Z_MIXD = L == DENSE ? 7 : 3;
+    static constexpr int X_MIXD = 7, Y_MIXD = L == DENSE ? 7 : L == PACKED ? 5 : 2, Z_MIXD = L == DENSE ? 7 : 3;
 
-    // ---- key slab (per key): rounds of KX_ROUND bytes, no head
+    // ---- key slab (per key): rounds of KX_ROUND bytes, no head.  VALUES keeps the PACKED key slab (one key
+    // slab per circuit in the reference's call shape; nothing to save there)
     static constexpr int KXS = 400;
     static constexpr int KYS = L == DENSE ? 400 : 240;
     static constexpr int KZS = L == DENSE ? 400 : 200;
@@ -98,7 +106,7 @@ struct Win {
         return R <= PERM_R ? start(R) : (R >= 10 ? TAIL0 : SLOT0 + ((R - PERM_R - 1) % NSLOT) * ROUND);
     }
 };
-template <int L> using WinX = Win<Geo<L>::X_HEAD, Geo<L>::X_ROUND, Geo<L>::X_TAIL, Geo<L>::XS>;
+template <int L> using WinX = Win<Geo<L>::X_HEAD, Geo<L>::X_ROUND, Geo<L>::X_TAIL, 1360>;  // VALUES: a valid type, never staged
 template <int L> using WinY = Win<Geo<L>::Y_HEAD, Geo<L>::Y_ROUND, Geo<L>::Y_TAIL, Geo<L>::YS>;
 template <int L> using WinZ = Win<Geo<L>::Z_HEAD, Geo<L>::Z_ROUND, Geo<L>::Z_TAIL, Geo<L>::ZS>;
 
@@ -217,6 +225,22 @@ inline void encrypt_assigned_mask(int col, uint8_t mask[AES_ROWS]) {
     }
     for (int i = 0; i < 16; ++i) set(1328 + i, true, true, false);
     for (int i = 0; i < 16; ++i) set(1344 + i, true, true, true);
+}
+
+// Pure-host: dense rows of the encrypt slab that the VALUES layout keeps (col 1: y of S-box / mul rows,
+// col 2: z of xor rows; col 0: none), in row order.
+inline void encrypt_values_mask(int col, uint8_t mask[AES_ROWS]) {
+    for (int r = 0; r < AES_ROWS; ++r) mask[r] = 0;
+    if (col == 0) return;
+    if (col == 2) { encrypt_assigned_mask(2, mask); return; }
+    // col 1: rows whose lookup is Sbox / GfMul2 / GfMul3
+    for (int R = 1; R <= 9; ++R) {
+        const int B = 32 + 144 * (R - 1);
+        for (int i = 0; i < 16; ++i) mask[B + i] = 1;
+        for (int k = 0; k < 16; ++k)
+            for (int t = 0; t < 4; ++t) mask[B + 16 + 7 * k + t] = MIX[k & 3][t] != 1;
+    }
+    for (int i = 0; i < 16; ++i) mask[1328 + i] = 1;
 }
 
 inline void key_assigned_mask(int col, uint8_t mask[KEY_ROWS]) {

@@ -34,6 +34,15 @@
  *                       assigns holds 0 (what the prover sees).
  *   AESW_LAYOUT_PACKED: only assigned cells, in row order: strides 1360/1056/608;
  *                       aesw_packed_index() gives dense row -> packed index.
+ *   AESW_LAYOUT_VALUES: only the cells whose VALUE a chip closure computes: y of
+ *                       the S-box and mul rows (src/chips/sbox_chip.rs:73-78,
+ *                       gf_mul_chip.rs:75-84), z of the xor rows
+ *                       (u8_xor_chip.rs:85-95), in row order: strides 0/448/608.
+ *                       Column x and the y cells of xor rows are copy_advice() of
+ *                       earlier cells in the reference, so a host that keeps the
+ *                       chips never reads them: 2.9x fewer bytes
+ *                       over PCIe.  x pointers are ignored; aesw_layout_index()
+ *                       gives dense row -> index.  Key slabs use the PACKED form.
  * The key-schedule witness per key is words_column (96 rows,
  * src/key_schedule.rs:98-187) plus 400 rows of set 0's x,y,z
  * (dense 400/400/400, packed 400/240/200).
@@ -69,7 +78,7 @@ enum aesw_status {
     AESW_ERR_UNSATISFIED = 8
 };
 
-enum aesw_layout { AESW_LAYOUT_DENSE = 0, AESW_LAYOUT_PACKED = 1 };
+enum aesw_layout { AESW_LAYOUT_DENSE = 0, AESW_LAYOUT_PACKED = 1, AESW_LAYOUT_VALUES = 2 };
 enum aesw_column { AESW_COL_X = 0, AESW_COL_Y = 1, AESW_COL_Z = 2 };
 
 typedef struct aesw_ctx aesw_ctx;
@@ -101,6 +110,8 @@ uint32_t aesw_column_stride(int layout, int col);     /* encrypt slab, bytes per
 uint32_t aesw_key_column_stride(int layout, int col); /* key slab, bytes per key */
 /* dense row -> packed index (or -1 if the reference never assigns the cell) */
 int aesw_packed_index(int col, int32_t idx[AESW_AES_ROWS]);
+/* the same for any layout (DENSE: identity; VALUES: -1 for cells the layout leaves out) */
+int aesw_layout_index(int layout, int col, int32_t idx[AESW_AES_ROWS]);
 int aesw_key_packed_index(int col, int32_t idx[AESW_KEY_ROWS]);
 /* FixedAes128Config::aes_callable (src/aes128.rs:303-325) as a pure function:
  * (set, first row) of the b-th encrypt() call in a K/N circuit; set 0 blocks

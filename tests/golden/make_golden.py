@@ -65,7 +65,7 @@ def slab_vectors():
     pt = np.frombuffer(b"".join(pt), np.uint8).reshape(-1, 16).copy()
     key = np.frombuffer(b"".join(key), np.uint8).reshape(-1, 16).copy()
     out = {"pt": pt, "keys": key}
-    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed")):
+    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed"), (ol.VALUES, "values")):
         w = orc.encrypt_witness(pt, key, layout=layout)
         k = orc.key_schedule_witness(key, layout=layout)
         for c in "xyz":

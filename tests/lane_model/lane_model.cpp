@@ -143,7 +143,7 @@ void run(const uint8_t *tab, const uint8_t *pt, const uint8_t *keys, int per_blo
                     }
                 }
             }
-            flush_col<WX>(R, sx, gx, fx);
+            if (G::HAS_X) flush_col<WX>(R, sx, gx, fx);
             flush_col<WY>(R, sy, gy, fy);
             flush_col<WZ>(R, sz, gz, fz);
         }
@@ -158,10 +158,13 @@ extern "C" int lane_model_run(const uint8_t *tab768, const uint8_t *pt, const ui
 #define GO(L, XT) run<L, XT>(tab768, pt, keys, per_block_keys, key_only, n, x, y, z, ct, wd, kx, ky, kz, rk)
     if (layout == DENSE) { if (xt_arith) GO(DENSE, true); else GO(DENSE, false); }
     else if (layout == PACKED) { if (xt_arith) GO(PACKED, true); else GO(PACKED, false); }
+    else if (layout == VALUES) { if (xt_arith) GO(VALUES, true); else GO(VALUES, false); }
     else return 1;
     return 0;
 #undef GO
 }
+
+extern "C" void lane_model_values_mask(int col, uint8_t *enc_mask) { encrypt_values_mask(col, enc_mask); }
 
 extern "C" void lane_model_masks(int col, uint8_t *enc_mask, uint8_t *key_mask) {
     encrypt_assigned_mask(col, enc_mask);
@@ -175,10 +178,12 @@ extern "C" void lane_model_window(int layout, int col, int out[6]) {
         out[0] = W::PERM_R; out[1] = W::NSLOT; out[2] = W::PERM_END; out[3] = W::TAIL0; out[4] = W::RAW; out[5] = W::BYTES;
     };
     if (layout == DENSE) { if (col == 0) fill(WinX<DENSE>{}); else if (col == 1) fill(WinY<DENSE>{}); else fill(WinZ<DENSE>{}); }
+    else if (layout == VALUES) { if (col == 0) fill(WinX<VALUES>{}); else if (col == 1) fill(WinY<VALUES>{}); else fill(WinZ<VALUES>{}); }
     else { if (col == 0) fill(WinX<PACKED>{}); else if (col == 1) fill(WinY<PACKED>{}); else fill(WinZ<PACKED>{}); }
 }
 
 extern "C" int lane_model_flush_forms_disagree(void) {
     return flush_forms_disagree<WinX<DENSE>>() + flush_forms_disagree<WinY<DENSE>>() + flush_forms_disagree<WinZ<DENSE>>() +
-           flush_forms_disagree<WinX<PACKED>>() + flush_forms_disagree<WinY<PACKED>>() + flush_forms_disagree<WinZ<PACKED>>();
+           flush_forms_disagree<WinX<PACKED>>() + flush_forms_disagree<WinY<PACKED>>() + flush_forms_disagree<WinZ<PACKED>>() +
+           flush_forms_disagree<WinY<VALUES>>() + flush_forms_disagree<WinZ<VALUES>>();
 }

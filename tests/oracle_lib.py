@@ -16,9 +16,9 @@ ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / "oracle" / "libaesw_oracle.so"
 
 AES_ROWS, KEY_ROWS, WORDS_ROWS, TABLE_ROWS = 1360, 400, 96, 66561
-DENSE, PACKED = 0, 1
-ENC_STRIDE = {DENSE: (1360, 1360, 1360), PACKED: (1360, 1056, 608)}
-KEY_STRIDE = {DENSE: (400, 400, 400), PACKED: (400, 240, 200)}
+DENSE, PACKED, VALUES = 0, 1, 2
+ENC_STRIDE = {DENSE: (1360, 1360, 1360), PACKED: (1360, 1056, 608), VALUES: (0, 448, 608)}
+KEY_STRIDE = {DENSE: (400, 400, 400), PACKED: (400, 240, 200), VALUES: (400, 240, 200)}
 
 OWitness = namedtuple("OWitness", "x y z ct")
 OKeyWitness = namedtuple("OKeyWitness", "w kx ky kz rk")
@@ -121,10 +121,25 @@ class Oracle:
         assert self.L.aesw_o_key_packed_index(col, _p(idx), None) == 0
         return idx
 
+    def values_mask(self, col: int) -> np.ndarray:
+        """Block-relative rows whose cell value a chip closure computes (not a copy_advice): y where the
+        S-box / mul2 / mul3 selector is enabled, z where the xor selector is; derived from the selectors the
+        restated synthesize() enables (src/chips/*.rs), not from the product's index tables."""
+        if not hasattr(self, "_vmask"):
+            with self.circuit(12, 1, np.zeros(16, np.uint8), np.zeros((1, 16), np.uint8), record_copies=False) as c:
+                sel = [c.selector(i)[KEY_ROWS:KEY_ROWS + AES_ROWS] for i in range(5)]  # range, xor, sbox, mul2, mul3
+            self._vmask = {0: np.zeros(AES_ROWS, bool), 1: (sel[2] | sel[3] | sel[4]).astype(bool), 2: sel[1].astype(bool)}
+        return self._vmask[col]
+
     def encrypt_witness(self, pt, keys, layout=PACKED, threads=8) -> OWitness:
         pt = np.ascontiguousarray(pt, np.uint8).reshape(-1, 16)
         keys = np.ascontiguousarray(keys, np.uint8)
         n = pt.shape[0]
+        if layout == VALUES:
+            d = self.encrypt_witness(pt, keys, layout=DENSE, threads=threads)
+            cols = [np.ascontiguousarray(getattr(d, c).reshape(n, AES_ROWS)[:, self.values_mask(i)]).reshape(-1)
+                    for i, c in enumerate("xyz")]
+            return OWitness(cols[0], cols[1], cols[2], d.ct)
         pbk = 0 if keys.size == 16 else 1
         sx, sy, sz = ENC_STRIDE[layout]
         x, y, z = np.zeros(n * sx, np.uint8), np.zeros(n * sy, np.uint8), np.zeros(n * sz, np.uint8)
@@ -136,6 +151,8 @@ class Oracle:
         return OWitness(x, y, z, ct)
 
     def key_schedule_witness(self, keys, layout=PACKED, threads=8) -> OKeyWitness:
+        if layout == VALUES:
+            layout = PACKED  # key slabs of the VALUES layout are the packed ones
         keys = np.ascontiguousarray(keys, np.uint8).reshape(-1, 16)
         n = keys.shape[0]
         kxs, kys, kzs = KEY_STRIDE[layout]

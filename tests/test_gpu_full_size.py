@@ -188,15 +188,15 @@ def test_config4_2p24_blocks_one_gpu(ctx, pkg, oracle):
         assert (lo, hi) == (r << 21, (r + 1) << 21)
 
 
-@pytest.mark.parametrize("layout_name", ["packed", "dense"])
+@pytest.mark.parametrize("layout_name", ["packed", "dense", "values"])
 @pytest.mark.parametrize("keymode", ["scheduled", "shared", "per_block"])
 def test_stress_byte_exact_2p18(ctx, pkg, oracle, layout_name, keymode):
     """Timing-dependent faults (store-data hazards, LDS ordering between a wave's flush and its next
     round) only show at scale: 2^18 + 37 blocks, every byte against the oracle, every key mode and layout."""
     import torch
-    layout = pkg.LAYOUT_PACKED if layout_name == "packed" else pkg.LAYOUT_DENSE
+    layout = {"packed": pkg.LAYOUT_PACKED, "dense": pkg.LAYOUT_DENSE, "values": pkg.LAYOUT_VALUES}[layout_name]
     n = (1 << 18) + 37
-    rng = np.random.default_rng(1000 + 10 * ["packed", "dense"].index(layout_name) + ["scheduled", "shared", "per_block"].index(keymode))
+    rng = np.random.default_rng(1000 + 10 * ["packed", "dense", "values"].index(layout_name) + ["scheduled", "shared", "per_block"].index(keymode))
     pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
     keys = rng.integers(0, 256, (n, 16), dtype=np.uint8)
     dpt = torch.from_numpy(pt).cuda()

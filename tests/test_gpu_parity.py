@@ -32,7 +32,7 @@ def _cmp(name, got, exp):
                              (name, bad.size, bad[0], got.reshape(-1)[bad[0]], exp.reshape(-1)[bad[0]]))
 
 
-@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED, ol.VALUES])
 @pytest.mark.parametrize("n", [1, 3, 16, 17, 63, 64, 65, 1000])
 def test_shared_key_small(ctx, oracle, layout, n):
     import torch
@@ -49,7 +49,7 @@ def test_shared_key_small(ctx, oracle, layout, n):
         _cmp(c, getattr(got.key, c), getattr(kexp, c))
 
 
-@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED, ol.VALUES])
 @pytest.mark.parametrize("n", [1, 5, 16, 33, 64, 257, 1000])
 def test_per_block_keys_small(ctx, oracle, layout, n):
     import torch
@@ -66,7 +66,7 @@ def test_per_block_keys_small(ctx, oracle, layout, n):
         _cmp(c, getattr(got.key, c), getattr(kexp, c))
 
 
-@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED, ol.VALUES])
 def test_per_block_keys_without_key_slab(ctx, oracle, layout):
     import torch
     pt, keys = _inputs(200)
@@ -176,7 +176,7 @@ def test_launch_options(pkg, oracle, waves, nt):
     c.set_option("waves_pbk", waves)
     c.set_option("store_mode", nt)
     pt, keys = _inputs(300)
-    for layout in (ol.DENSE, ol.PACKED):
+    for layout in (ol.DENSE, ol.PACKED, ol.VALUES):
         for k_host in (keys[0], keys):
             got = c.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(np.ascontiguousarray(k_host)).cuda(),
                                     layout=layout, key_slab=True)
@@ -190,7 +190,7 @@ def test_launch_options(pkg, oracle, waves, nt):
     c.close()
 
 
-@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED, ol.VALUES])
 def test_schedule_key_then_encrypt(pkg, oracle, layout):
     """The reference's call shape: schedule_key() once, encrypt() n times
     (benches/aes128.rs:50-53); encrypt before schedule_key fails like the
@@ -333,7 +333,7 @@ def test_host_pointer_path(ctx, oracle):
     pt, keys = _inputs(5000)
     ctx.set_option("chunk_blocks", 1024)  # force several pipeline stages
     try:
-        for layout in (ol.DENSE, ol.PACKED):
+        for layout in (ol.DENSE, ol.PACKED, ol.VALUES):
             for k_host in (keys[0], keys):
                 got = ctx.encrypt_witness_host(pt, k_host, layout=layout, want_ct=True, key_slab=True)
                 exp = oracle.encrypt_witness(pt, k_host, layout=layout)
@@ -377,7 +377,7 @@ def test_streaming_host_path(ctx, pkg, oracle):
     pt, keys = _inputs(5000)
     ctx.set_option("chunk_blocks", 1024)
     try:
-        for layout in (ol.DENSE, ol.PACKED):
+        for layout in (ol.DENSE, ol.PACKED, ol.VALUES):
             strides = ol.ENC_STRIDE[layout]
             for k_host in (None, keys[3], keys):
                 if k_host is None:
@@ -507,7 +507,7 @@ def test_committed_golden_fixtures(ctx):
     from pathlib import Path
     g = np.load(Path(__file__).resolve().parent / "golden" / "slab_vectors.npz")
     dpt, dkeys = torch.from_numpy(g["pt"]).cuda(), torch.from_numpy(g["keys"]).cuda()
-    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed")):
+    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed"), (ol.VALUES, "values")):
         got = ctx.encrypt_witness(dpt, dkeys, layout=layout, want_ct=True, key_slab=True)
         shared = ctx.encrypt_witness(dpt, dkeys[4].contiguous(), layout=layout)
         kw = ctx.key_schedule_witness(dkeys, layout=layout)

@@ -44,7 +44,7 @@ def _check(bufs, name, exp):
     assert np.all(got[exp.size:] == 0xAB), "%s: wrote past the end of the buffer" % name
 
 
-@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED, ol.VALUES])
 @pytest.mark.parametrize("xt", [0, 1])
 @pytest.mark.parametrize("n", [1, 2, 7, 15, 16, 17, 31, 33, 100])
 def test_encrypt_matches_oracle(model, oracle, layout, xt, n):
@@ -77,7 +77,7 @@ def test_key_only_matches_oracle(model, oracle, layout):
         _check(bufs, c, getattr(kexp, c))
 
 
-@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED, ol.VALUES])
 def test_arbitrary_tables(model, layout):
     """mul2/mul3 need not be xtime tables: the table path follows whatever the host passes."""
     rng = np.random.default_rng(5)
@@ -100,11 +100,20 @@ def test_masks_match_oracle(model, oracle):
         assert np.array_equal(km, oracle.key_assigned_mask(col))
 
 
+def test_values_mask_matches_oracle(model, oracle):
+    """The VALUES layout keeps exactly the cells a chip closure computes (y: S-box / mul rows, z: xor rows)."""
+    for col in range(3):
+        m = np.zeros(1360, np.uint8)
+        model.lane_model_values_mask(col, _p(m))
+        assert np.array_equal(m.astype(bool), oracle.values_mask(col))
+    assert oracle.values_mask(1).sum() == 448 and oracle.values_mask(2).sum() == 608
+
+
 def test_window_geometry(model):
     """Staging windows: permanent head >= one line, slots cover the unflushed
     bytes, stride = 16 (mod 32) bytes for conflict-free LDS writes."""
-    expect = {(0, 0): 496, (0, 1): 496, (0, 2): 496, (1, 0): 496, (1, 1): 400, (1, 2): 368}
-    rounds = {(0, 0): 144, (0, 1): 144, (0, 2): 144, (1, 0): 144, (1, 1): 112, (1, 2): 64}
+    expect = {(0, 0): 496, (0, 1): 496, (0, 2): 496, (1, 0): 496, (1, 1): 400, (1, 2): 368, (2, 1): 368, (2, 2): 368}
+    rounds = {(0, 0): 144, (0, 1): 144, (0, 2): 144, (1, 0): 144, (1, 1): 112, (1, 2): 64, (2, 1): 48, (2, 2): 64}
     for (layout, col), nbytes in expect.items():
         out = (C.c_int * 6)()
         model.lane_model_window(layout, col, out)
@@ -126,7 +135,7 @@ def test_golden_vectors(model, oracle):
     from pathlib import Path
     g = np.load(Path(__file__).resolve().parent / "golden" / "slab_vectors.npz")
     tab = np.concatenate(oracle.tables())
-    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed")):
+    for layout, name in ((ol.DENSE, "dense"), (ol.PACKED, "packed"), (ol.VALUES, "values")):
         bufs = _run(model, tab, g["pt"], g["keys"], 1, 0, layout, 1)
         for c in "xyz":
             _check(bufs, c, g["%s_%s" % (name, c)])

@@ -23,7 +23,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 threads = min(64, os.cpu_count() or 8)
 t0 = time.time()
 for it in range(iters):
-    layout = int(rng.integers(0, 2))
+    layout = int(rng.integers(0, 3))
     keymode = int(rng.integers(0, 3))
     n = int(rng.integers(1 << 16, 1 << 18)) + int(rng.integers(0, 64))
     ctx = pkg.Context(0)
