@@ -35,35 +35,52 @@ struct AesWitness {
     uint64_t n = 0;
     uint8_t key[16] = {0};
     std::vector<uint8_t> pt;                        // n*16
-    std::vector<uint8_t> x, y, z;                   // n*1360 each
+    std::vector<uint8_t> x, y, z;                   // dense: n*1360 each; values only: none / n*448 / n*608
     std::vector<uint8_t> key_w, key_x, key_y, key_z;  // 96, 400, 400, 400
+    bool values_only = false;                       // AESW_LAYOUT_VALUES: only what the chips' value closures read
+    size_t sx = AES_ROWS_, sy = AES_ROWS_, sz = AES_ROWS_;  // bytes per block
+    int32_t iy[AESW_AES_ROWS], iz[AESW_AES_ROWS];   // values only: dense row -> index (-1: a copied cell)
 
     // aesw_schedule_key + aesw_encrypt_witness (host-pointer entry points).
-    static std::shared_ptr<const AesWitness> generate(aesw_ctx *ctx, const uint8_t key[16], const uint8_t *pts, uint64_t n) {
+    static std::shared_ptr<const AesWitness> generate(aesw_ctx *ctx, const uint8_t key[16], const uint8_t *pts, uint64_t n,
+                                                      bool values_only = false) {
         auto w = std::make_shared<AesWitness>();
         w->n = n;
+        w->values_only = values_only;
         std::memcpy(w->key, key, 16);
         w->pt.assign(pts, pts + 16 * n);
-        w->x.resize(n * AES_ROWS_); w->y.resize(n * AES_ROWS_); w->z.resize(n * AES_ROWS_);
+        const int layout = values_only ? AESW_LAYOUT_VALUES : AESW_LAYOUT_DENSE;
+        w->sx = aesw_column_stride(layout, 0); w->sy = aesw_column_stride(layout, 1); w->sz = aesw_column_stride(layout, 2);
+        w->x.resize(n * w->sx); w->y.resize(n * w->sy); w->z.resize(n * w->sz);
+        if (aesw_layout_index(layout, 1, w->iy) != AESW_OK || aesw_layout_index(layout, 2, w->iz) != AESW_OK)
+            throw Error(Error::Synthesis, "aesw_layout_index failed");
         w->key_w.resize(AESW_WORDS_ROWS); w->key_x.resize(AESW_KEY_ROWS); w->key_y.resize(AESW_KEY_ROWS); w->key_z.resize(AESW_KEY_ROWS);
         aesw_key_slab ks{w->key_w.data(), w->key_x.data(), w->key_y.data(), w->key_z.data()};
         int rc = aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks);
         if (rc == AESW_OK && n)
-            rc = aesw_encrypt_witness(ctx, pts, nullptr, 0, n, AESW_LAYOUT_DENSE, w->x.data(), w->y.data(), w->z.data(), nullptr, nullptr);
+            rc = aesw_encrypt_witness(ctx, pts, nullptr, 0, n, layout, w->sx ? w->x.data() : nullptr, w->y.data(), w->z.data(), nullptr, nullptr);
         if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("device witness generation failed: ") + aesw_strerror(rc));
         return w;
     }
 };
 
-// Where the gadget currently is inside a slab: three column arrays and a row.
+// Where the gadget currently is inside a slab: three column arrays and a row.  With the values-only
+// witness (iy/iz set) x is absent and y holds only S-box / mul outputs: the copied cells have nothing
+// to be checked against, exactly as in the reference, where copy_advice() takes the source cell's value.
 struct WitnessCursor {
     const uint8_t *x = nullptr, *y = nullptr, *z = nullptr;
     uint64_t row = 0, rows = 0;
+    const int32_t *iy = nullptr, *iz = nullptr;
+    const uint8_t *pt = nullptr;  // the block's plaintext literal (src/aes128.rs:187), used when x is absent
+    uint8_t yv(uint64_t r) const { return iy ? y[iy[r]] : y[r]; }
+    uint8_t zv(uint64_t r) const { return iz ? z[iz[r]] : z[r]; }
     void expect_x(uint64_t r, Fp v, const char *what) const {
         // copy_advice carries the source cell's value; the device's x/y byte for the same cell must agree
+        if (!x) return;
         if (r >= rows || x[r] != v) throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what);
     }
     void expect_y(uint64_t r, Fp v, const char *what) const {
+        if (iy) return;
         if (r >= rows || y[r] != v) throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what);
     }
 };
@@ -109,7 +126,7 @@ public:
             x.copy_advice(region, config.x, 0);
             y.copy_advice(region, config.y, 0);
             // was: xor_bytes(x_copied.value, y_copied.value) (:85-95) -- now the device's byte
-            return region.assign_advice(config.z, 0, [c, r] { return Value::of(c->z[r]); });
+            return region.assign_advice(config.z, 0, [c, r] { return Value::of(c->zv(r)); });
         });
         if (x.val.known) cur->expect_x(r, x.val.v, "xor x");
         if (y.val.known) cur->expect_y(r, y.val.v, "xor y");
@@ -137,7 +154,7 @@ public:
             region.enable_selector(config.q, 0);
             x.copy_advice(region, config.x, 0);
             // was: sub_byte(x_copied.value) (:73-78)
-            return region.assign_advice(config.y, 0, [c, r] { return Value::of(c->y[r]); });
+            return region.assign_advice(config.y, 0, [c, r] { return Value::of(c->yv(r)); });
         });
         if (x.val.known) cur->expect_x(r, x.val.v, "sbox x");
         cur->row++;
@@ -166,7 +183,7 @@ public:
             region.enable_selector(config.q, 0);
             x.copy_advice(region, config.x, 0);
             // was: Fp::from($dict[x]) (:75-84)
-            return region.assign_advice(config.y, 0, [c, r] { return Value::of(c->y[r]); });
+            return region.assign_advice(config.y, 0, [c, r] { return Value::of(c->yv(r)); });
         });
         if (x.val.known) cur->expect_x(r, x.val.v, "gf mul x");
         cur->row++;
@@ -367,7 +384,9 @@ public:
         const uint64_t b = total++;  // the b-th encrypt() call reads slab b
         if (b >= wit->n) throw Error(Error::Mismatch, "more encrypt() calls than blocks in the device witness");
         if (std::memcmp(plaintext, wit->pt.data() + 16 * b, 16) != 0) throw Error(Error::Mismatch, "plaintext differs from the device witness's block");
-        cur = WitnessCursor{wit->x.data() + b * AES_ROWS_, wit->y.data() + b * AES_ROWS_, wit->z.data() + b * AES_ROWS_, 0, AES_ROWS_};
+        cur = WitnessCursor{wit->sx ? wit->x.data() + b * wit->sx : nullptr, wit->y.data() + b * wit->sy, wit->z.data() + b * wit->sz, 0, AES_ROWS_,
+                            wit->values_only ? wit->iy : nullptr, wit->values_only ? wit->iz : nullptr, wit->pt.data() + 16 * b};
+        if (bulk_assign && wit->values_only) throw Error(Error::Synthesis, "bulk assignment needs whole columns, not the values-only witness");
         if (bulk_assign && graph_ready) return encrypt_bulk(layouter);
         const size_t copies_before = layouter.copies().size();
         const uint64_t block_start = layouter.column_height(get_advices()[0]);
@@ -475,7 +494,7 @@ private:
         // :176-192 "Assign plaintext" -- was Fp::from(p as u64) of the literal (:187)
         auto assigned_plaintext = layouter.assign_region<std::vector<AssignedCell>>("Assign plaintext", [&](Region &region) {
             std::vector<AssignedCell> v;
-            for (uint64_t i = 0; i < 16; ++i) v.push_back(region.assign_advice(adv[0], i, [c, i] { return Value::of(c->x[i]); }));
+            for (uint64_t i = 0; i < 16; ++i) v.push_back(region.assign_advice(adv[0], i, [c, i] { return Value::of(c->x ? c->x[i] : c->pt[i]); }));
             return v;
         });
         cur.row = 16;

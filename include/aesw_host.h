@@ -29,13 +29,17 @@ typedef struct aesw_host_circuit aesw_host_circuit;
  * FixedAes128Config<K, n_sets> circuit of 2^k rows.  with_witnesses = 0 mimics
  * keygen (value closures are never evaluated).  skip_schedule_key = 1 omits
  * schedule_key() to exercise the reference's expect("Keys should be scheduled").
- * bulk_assign = 1: the first block goes through the reference's 1 360 one-row
- * regions, every later block is assigned as ONE 1 360-row region that replays
- * the first block's copy graph; cells, selectors and equality
- * constraints are the same, only the region count differs. */
+ * assign_mode = 1 (bulk): the first block goes through the reference's 1 360
+ * one-row regions, every later block is assigned as ONE 1 360-row region that
+ * replays the first block's copy graph; cells, selectors and
+ * equality constraints are the same, only the region count differs.
+ * assign_mode = 2 (values only): the reference's regions, fed by the
+ * AESW_LAYOUT_VALUES witness -- the device hands over only the S-box / mul / xor
+ * outputs the value closures read; every other cell takes its value through
+ * copy_advice(), as in the reference. */
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16],
                               const uint8_t *pts, uint64_t n, int with_witnesses,
-                              int skip_schedule_key, int bulk_assign, aesw_host_circuit **out);
+                              int skip_schedule_key, int assign_mode, aesw_host_circuit **out);
 /* key_schedule.rs TestCircuit: 3 advice columns + words_column, schedule_keys only. */
 int aesw_host_key_circuit_run(aesw_ctx *ctx, uint32_t k, const uint8_t key[16],
                               aesw_host_circuit **out);

@@ -69,6 +69,27 @@ def test_random_circuit_two_sets(ctx, pkg, oracle):
                 assert np.array_equal(mock.ciphertext(b), o.ciphertext(b))
 
 
+def test_values_only_witness_fills_the_whole_circuit(ctx, pkg, oracle):
+    """AESW_LAYOUT_VALUES hands the host only the S-box / mul / xor outputs (1 056 B per block).  Running the
+    reference's regions on it -- copy_advice() carrying every other value, as in the reference -- must assign
+    the very same circuit as the restated synthesize(): every advice cell, selector, copy and the fixed column."""
+    rng = np.random.default_rng(0xA35128 + 9)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (60, 16), dtype=np.uint8)
+    pts[7] = key ^ 0xFF   # S_BOX[0xff]
+    with pkg.HostCircuit.aes(ctx, 16, 2, key, pts, values_only=True) as mock:
+        rc, msg = mock.verify()
+        assert rc == 0, msg
+        with oracle.circuit(16, 2, key, pts) as o:
+            _same_assembly(mock, o)
+            for b in (0, 7, 45, 46, 59):
+                assert np.array_equal(mock.ciphertext(b), o.ciphertext(b))
+    # the reference's own integration test, on the values-only witness
+    with pkg.HostCircuit.aes(ctx, 20, 3, np.zeros(16, np.uint8), np.zeros((1000, 16), np.uint8), values_only=True) as mock:
+        assert mock.verify() == (0, "")
+        assert mock.ciphertext(999).tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
+
+
 def test_bulk_assign_equals_per_region(ctx, pkg, oracle):
     """one 1 360-row region per block (after the first) == the reference's 1 360 one-row regions:
     same advice cells, selectors, fixed column and the same SET of equality constraints; far fewer regions."""
