@@ -70,6 +70,25 @@ int main(int argc, char **argv) {
     uint32_t set; uint64_t row;
     bad |= aesw_block_placement(20, 3, 769, &set, &row) != AESW_OK || set != 1 || row != 0;
     printf("%llu blocks, dense layout: %s\n", (unsigned long long)n, bad ? "MISMATCH" : "ok");
+
+    /* The values-only layout: just the cells the chips' value closures read (y of S-box / mul rows,
+     * z of xor rows), 1 056 B per block; it must agree with the dense columns through aesw_layout_index. */
+    {
+        int32_t iy[AESW_AES_ROWS], iz[AESW_AES_ROWS];
+        uint8_t *vy = aesw_host_alloc(n * aesw_column_stride(AESW_LAYOUT_VALUES, 1));
+        uint8_t *vz = aesw_host_alloc(n * aesw_column_stride(AESW_LAYOUT_VALUES, 2));
+        int vbad = !vy || !vz || aesw_layout_index(AESW_LAYOUT_VALUES, 1, iy) != AESW_OK ||
+                   aesw_layout_index(AESW_LAYOUT_VALUES, 2, iz) != AESW_OK;
+        if (!vbad) vbad = aesw_encrypt_witness(ctx, pt, NULL, 0, n, AESW_LAYOUT_VALUES, NULL, vy, vz, NULL, NULL) != AESW_OK;
+        for (uint64_t b = 0; b < n && !vbad; ++b)
+            for (int r = 0; r < AESW_AES_ROWS; ++r) {
+                if (iy[r] >= 0) vbad |= vy[b * 448 + iy[r]] != y[b * 1360 + r];
+                if (iz[r] >= 0) vbad |= vz[b * 608 + iz[r]] != z[b * 1360 + r];
+            }
+        printf("%llu blocks, values-only layout: %s\n", (unsigned long long)n, vbad ? "MISMATCH" : "ok");
+        bad |= vbad;
+        aesw_host_free(vy); aesw_host_free(vz);
+    }
     aesw_host_free(x); aesw_host_free(y); aesw_host_free(z);
     free(pt); free(ct);
     aesw_destroy(ctx);

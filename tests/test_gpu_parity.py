@@ -131,7 +131,7 @@ def test_sbox_ff_differs_from_fips(ctx, pkg, oracle):
     fctx.close()
 
 
-@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED])
+@pytest.mark.parametrize("layout", [ol.DENSE, ol.PACKED, ol.VALUES])
 def test_generic_table_path(ctx, pkg, oracle, layout):
     """Tables that are NOT xtime tables force the LDS-lookup MixColumns path;
     the device must follow them (the host's lookup table is the arbiter)."""
@@ -245,7 +245,7 @@ def test_group_striding(pkg, oracle, cap):
     c = pkg.Context(0)
     c.set_option("grid_cap", cap)
     pt, keys = _inputs(1111)
-    for layout in (ol.DENSE, ol.PACKED):
+    for layout in (ol.DENSE, ol.PACKED, ol.VALUES):
         for k_host in (keys[0], keys):
             got = c.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(np.ascontiguousarray(k_host)).cuda(),
                                     layout=layout, want_ct=True, key_slab=True)
