@@ -17,7 +17,7 @@ import bench  # noqa: E402
 
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 workload = sys.argv[2] if len(sys.argv) > 2 else "c1"
-layout = pkg.LAYOUT_PACKED if (len(sys.argv) <= 3 or sys.argv[3] == "packed") else pkg.LAYOUT_DENSE
+layout = {"packed": pkg.LAYOUT_PACKED, "dense": pkg.LAYOUT_DENSE, "values": pkg.LAYOUT_VALUES}[sys.argv[3] if len(sys.argv) > 3 else "packed"]
 variants = []
 if len(sys.argv) > 4 and sys.argv[4] == "cap":
     for w in (4, 3, 2):
