@@ -127,6 +127,8 @@ class Runner:
             for i in range(steps):
                 self.launch(i, sp)
         e1.record()
+        while not e1.query():  # poll: a blocking wait adds its wake-up latency to a short timed region
+            pass
         torch.cuda.synchronize()
         t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks is taken by the caller
         if barrier:
