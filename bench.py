@@ -179,8 +179,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("AESW_BENCH_FORCE_DIST"):  # the env switch rehearses the RCCL path with one rank
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if "AESW_BENCH_DEVICE" in os.environ:  # rehearsal: several ranks on one GPU (gloo only)
             local_rank = int(os.environ["AESW_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
@@ -188,7 +192,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(a.backend)
-    dev = local_rank if world > 1 else 0
+    dev = local_rank if dist is not None else 0
     torch.cuda.set_device(dev)
     ctx = pkg.Context(dev)
     for opt in a.option:
@@ -196,7 +200,7 @@ def main():
         ctx.set_option(k, int(v))
     layout = {"packed": pkg.LAYOUT_PACKED, "dense": pkg.LAYOUT_DENSE, "values": pkg.LAYOUT_VALUES}[a.layout]
     host_bufs = None
-    if rank == 0 and world == 1 and not a.no_extras:
+    if rank == 0 and dist is None and not a.no_extras:
         # Page-locked buffers of the PCIe-inclusive extra are taken first, as a host would at start-up.
         try:
             nn_host = 1 << 20
@@ -252,7 +256,7 @@ def main():
     }
 
     extras = {}
-    if rank == 0 and world == 1 and not a.no_extras:
+    if rank == 0 and dist is None and not a.no_extras:
         # secondary measurements (not `value`): the other layout and BASELINE configs[2]
         del runner
         torch.cuda.empty_cache()
@@ -423,7 +427,7 @@ def main():
         except Exception as e:
             extras["assemble_fr"] = {"error": str(e)}
         line["extra"] = extras
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if rank == 0 and dist is None and not a.no_cpu:
         line["cpu_baseline"] = cpu_baseline()
     elif rank == 0:
         line["cpu_baseline"] = None
