@@ -263,20 +263,21 @@ def test_group_striding(pkg, oracle, cap):
 def test_unaligned_column_buffers(ctx, oracle):
     """Column pointers need only 16-byte alignment (128 is just faster)."""
     import torch
-    pt, keys = _inputs(200)
-    for layout in (ol.DENSE, ol.PACKED):
-        strides = ol.ENC_STRIDE[layout]
-        bufs = [torch.full((200 * s + 4096,), 0xCD, dtype=torch.uint8, device="cuda") for s in strides]
-        offs = (16, 48, 112)
-        import halo2_aes_amd as pkg
-        out = pkg.Witness(*[b[o:o + 200 * s] for b, o, s in zip(bufs, offs, strides)], None, None)
-        ctx.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(keys[0]).cuda(), layout=layout, out=out)
-        torch.cuda.synchronize()
-        exp = oracle.encrypt_witness(pt, keys[0], layout=layout)
-        for b, o, s, name in zip(bufs, offs, strides, "xyz"):
-            h = b.cpu().numpy()
-            assert np.array_equal(h[o:o + 200 * s], getattr(exp, name)), name
-            assert np.all(h[:o] == 0xCD) and np.all(h[o + 200 * s:] == 0xCD), "wrote outside the column buffer"
+    import halo2_aes_amd as pkg
+    for n in (200, 37, 1):
+        pt, keys = _inputs(n)
+        for layout in (ol.DENSE, ol.PACKED, ol.VALUES):
+            strides = ol.ENC_STRIDE[layout]
+            bufs = [torch.full((n * s + 4096,), 0xCD, dtype=torch.uint8, device="cuda") for s in strides]
+            offs = (16, 48, 112)
+            out = pkg.Witness(*[b[o:o + n * s] for b, o, s in zip(bufs, offs, strides)], None, None)
+            ctx.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(keys[0]).cuda(), layout=layout, out=out)
+            torch.cuda.synchronize()
+            exp = oracle.encrypt_witness(pt, keys[0], layout=layout)
+            for b, o, s, name in zip(bufs, offs, strides, "xyz"):
+                h = b.cpu().numpy()
+                assert np.array_equal(h[o:o + n * s], getattr(exp, name)), name
+                assert np.all(h[:o] == 0xCD) and np.all(h[o + n * s:] == 0xCD), "wrote outside the column buffer"
 
 
 def test_config1_single_block(ctx):
