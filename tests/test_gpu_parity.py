@@ -500,6 +500,16 @@ def test_plain_c_host(pkg, tmp_path):
     assert "66e94bd4ef8a2c3b884cfa59ca342b2e" in out.stdout and "ok" in out.stdout
 
 
+def test_end_to_end_example(pkg):
+    """examples/end_to_end.py: device witness -> synthesize() + MockProver -> values-only -> Fr columns -> keygen data."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("aesw_end_to_end", Path(__file__).resolve().parent.parent / "examples" / "end_to_end.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(n=150, k=16, n_sets=4)
+
+
 def test_committed_golden_fixtures(ctx):
     """The HIP path against tests/golden/slab_vectors.npz directly (no oracle in the loop): the reference's
     zero vector, FIPS-197 App. B / C.1, the S_BOX[0xff] block and seeded random blocks, both layouts,
