@@ -27,6 +27,7 @@ struct aesw_ctx {
     int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
     int nt = 2;  // store flavour: 0 plain, 1 nontemporal, 2 write-through (sc1, default: nothing left dirty in L2 at kernel end)
+    int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
     bool xcd_remap = false;
     int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
@@ -354,6 +355,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
         ctx->nt = (int)value;
         return AESW_OK;
     }
+    if (!std::strcmp(name, "fr_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_nt = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
     if (!std::strcmp(name, "lds_pad")) { if (value < 0 || value > 120 * 1024) return AESW_ERR_INVALID_ARG; ctx->lds_pad = value; return AESW_OK; }
@@ -498,7 +500,7 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
     p.sx = aesw_column_stride(layout, 0); p.sy = aesw_column_stride(layout, 1); p.sz = aesw_column_stride(layout, 2);
     p.kxs = aesw_key_column_stride(layout, 0); p.kys = aesw_key_column_stride(layout, 1); p.kzs = aesw_key_column_stride(layout, 2);
     p.packed = layout == AESW_LAYOUT_PACKED;
-    HIP_TRY(ctx, launch_assemble(p, as_fr != 0, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_assemble(p, as_fr != 0, ctx->fr_nt, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 
@@ -508,7 +510,7 @@ int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cell
     if (!d_cells || !d_fr || !aligned16(d_fr)) return AESW_ERR_INVALID_ARG;
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
-    HIP_TRY(ctx, launch_expand_fr(d_cells, n_cells, ctx->d_fr_lut, d_fr, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_expand_fr(d_cells, n_cells, ctx->d_fr_lut, d_fr, ctx->fr_nt, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 

@@ -50,7 +50,7 @@ struct AssembleParams {
     uint32_t sx, sy, sz, kxs, kys, kzs;  // bytes per block / per key
     int packed;
 };
-hipError_t launch_assemble(const AssembleParams &p, bool as_fr, hipStream_t s);
-hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, hipStream_t s);
+hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int store_mode, hipStream_t s);
+hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int store_mode, hipStream_t s);
 
 }  // namespace aesw

@@ -524,6 +524,7 @@ __global__ void __launch_bounds__(256) table_kernel(const uint8_t *__restrict__ 
 // One lane writes one 16-byte half cell, so a wave stores 1 KiB contiguously;
 // each wave owns UNROLL KiB-pieces per trip and issues all its byte loads, then
 // all LUT reads, then all stores, to keep >= 8 KiB in flight per wave.
+template <int NT>
 __global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restrict__ cells, uint64_t n_cells,
                                                        const u32x4 *__restrict__ fr_lut, u32x4 *__restrict__ out) {
     __shared__ u32x4 lut[512];
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restric
 #pragma unroll
         for (int j = 0; j < UNROLL; ++j) {
             const uint64_t i = base + j * 64 + lane;
-            if (i < total) __builtin_nontemporal_store(lut[v[j] * 2 + (uint32_t)(i & 1)], &out[i]);
+            if (i < total) gstore<NT>(&out[i], lut[v[j] * 2 + (uint32_t)(i & 1)]);
         }
     }
 }
@@ -580,7 +581,7 @@ __device__ __forceinline__ uint32_t advice_cell(const AssembleParams &a, uint32_
     return idx >= 0 ? sc[b * stride + idx] : 0u;
 }
 
-template <bool AS_FR>
+template <bool AS_FR, int NT>
 __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
     __shared__ u32x4 lut[AS_FR ? 512 : 1];
     if (AS_FR) {
@@ -596,7 +597,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells * 2; i += stride) {
             const uint64_t cell = i >> 1;
             const uint32_t v = advice_cell(a, (uint32_t)(cell >> a.k), cell & (rows - 1));
-            __builtin_nontemporal_store(lut[v * 2 + (uint32_t)(i & 1)], &out[i]);
+            gstore<NT>(&out[i], lut[v * 2 + (uint32_t)(i & 1)]);
         }
     } else {
         // one lane = four consecutive cells of one column (rows is a multiple of 4)
@@ -716,22 +717,27 @@ hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t
     return hipGetLastError();
 }
 
-hipError_t launch_assemble(const AssembleParams &p, bool as_fr, hipStream_t s) {
+hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int nt, hipStream_t s) {
     const uint64_t cells = (uint64_t)(3 * p.n_sets + 1) << p.k;
     uint64_t blocks = ((as_fr ? cells * 2 : cells / 4) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks == 0) blocks = 1;
-    if (as_fr) hipLaunchKernelGGL(assemble_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(assemble_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    if (!as_fr) hipLaunchKernelGGL((assemble_kernel<false, 0>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (nt == 2) hipLaunchKernelGGL((assemble_kernel<true, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else if (nt == 1) hipLaunchKernelGGL((assemble_kernel<true, 1>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((assemble_kernel<true, 0>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, hipStream_t s) {
+hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int nt, hipStream_t s) {
     if (n_cells == 0) return hipSuccess;
     uint64_t blocks = (n_cells * 2 + 256 * 8 - 1) / (256 * 8);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(expand_fr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells,
-                       reinterpret_cast<const u32x4 *>(fr_lut), reinterpret_cast<u32x4 *>(out));
+    const u32x4 *lut = reinterpret_cast<const u32x4 *>(fr_lut);
+    u32x4 *o = reinterpret_cast<u32x4 *>(out);
+    if (nt == 2) hipLaunchKernelGGL(expand_fr_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells, lut, o);
+    else if (nt == 1) hipLaunchKernelGGL(expand_fr_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells, lut, o);
+    else hipLaunchKernelGGL(expand_fr_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells, lut, o);
     return hipGetLastError();
 }
 
