@@ -27,6 +27,7 @@ struct aesw_ctx {
     int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
     int nt = 2;  // store flavour: 0 plain, 1 nontemporal, 2 write-through (sc1, default: nothing left dirty in L2 at kernel end)
+    int key_nt = 1;  // store flavour of key_kernel (one contiguous flush per column at the end): nontemporal 4-9 % ahead of sc1 (tools/keysweep.py)
     int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
     bool xcd_remap = false;
@@ -355,6 +356,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
         ctx->nt = (int)value;
         return AESW_OK;
     }
+    if (!std::strcmp(name, "key_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->key_nt = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "fr_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_nt = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
@@ -408,7 +410,7 @@ int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, co
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     KeyParams kp{d_key, ctx->d_tables, ko, ctx->d_rk, 1};
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->nt, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, reinterpret_cast<hipStream_t>(stream)));
     ctx->have_key = true;
     return AESW_OK;
 }
@@ -442,7 +444,7 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
     if (!per_block_keys && kemit) {
         // shared key: its schedule witness is one key slab
         KeyParams kp{d_keys, ctx->d_tables, ko, nullptr, 1};
-        HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->nt, s));
+        HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, s));
     }
     const int km = per_block_keys ? 0 : (d_keys ? 1 : 2);
     EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, d_x, d_y, d_z, d_ct,
@@ -466,7 +468,7 @@ int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint6
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     KeyParams kp{d_keys, ctx->d_tables, KeyOut{d_w, d_kx, d_ky, d_kz}, d_rk, n};
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves_key(ctx, layout), ctx->nt, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves_key(ctx, layout), ctx->key_nt, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 

@@ -216,8 +216,8 @@ int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint
 /* name: "waves_shared" / "waves_pbk" (waves per group, 0 = auto, 1..4),
  * "store_mode" (0 plain, 1 nontemporal, 2 write-through sc1), "nt_stores" (0/1), "grid_cap" (max workgroups per launch, 0 = one per block
  * group), "xcd_remap" (0/1), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
- * pipeline, default 2^15), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" (store flavour
- * of the Fr-expanding kernels, default 1).
+ * pipeline, default 2^15), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
+ * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1).
  * Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);

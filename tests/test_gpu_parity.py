@@ -83,11 +83,16 @@ def test_per_block_keys_without_key_slab(ctx, oracle, layout):
 def test_key_schedule_kernel(ctx, oracle, layout, n):
     import torch
     _, keys = _inputs(n)
-    got = ctx.key_schedule_witness(torch.from_numpy(keys).cuda(), layout=layout)
-    torch.cuda.synchronize()
     exp = oracle.key_schedule_witness(keys, layout=layout)
-    for c in ("w", "kx", "ky", "kz", "rk"):
-        _cmp(c, getattr(got, c), getattr(exp, c))
+    try:
+        for mode in (1, 0, 2):  # nontemporal (default), plain, write-through
+            ctx.set_option("key_store_mode", mode)
+            got = ctx.key_schedule_witness(torch.from_numpy(keys).cuda(), layout=layout)
+            torch.cuda.synchronize()
+            for c in ("w", "kx", "ky", "kz", "rk"):
+                _cmp(c, getattr(got, c), getattr(exp, c))
+    finally:
+        ctx.set_option("key_store_mode", 1)
 
 
 def test_zero_vector_and_fips_kats(ctx, oracle):
