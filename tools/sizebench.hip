@@ -10,14 +10,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 constexpr int XS = 1360, YS = 1056, ZS = 608;
 
-template <bool SC1>
+template <int SC1>  // 0 plain, 1 sc1 (write-through), 2 nontemporal
 __device__ __forceinline__ void st(u32x4 *p, u32x4 v) {
-    if (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if (SC1 == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    else if (SC1 == 2) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 
 // every wave streams its 16-block range of each column, ROUNDS slices per column in turn (like the per-round flush)
-template <bool SC1>
+template <int SC1>
 __global__ void __launch_bounds__(256) k_units(uint8_t *x, uint8_t *y, uint8_t *z, uint64_t nblk, int spin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const uint64_t blk0 = ((uint64_t)blockIdx.x * waves + wave) * 16;
@@ -45,7 +46,7 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     printf("spin=%d\n%-8s %-6s %-6s %10s %10s\n", spin, "log2n", "waves", "sc1", "us/launch", "GB/s");
-    for (int sc1 = 0; sc1 < 2; ++sc1)
+    for (int sc1 = 0; sc1 < 3; ++sc1)
         for (int waves : {4, 1})
             for (int lg = 14; lg <= 20; ++lg) {
                 const uint64_t nblk = 1ull << lg;
@@ -56,8 +57,9 @@ int main(int argc, char **argv) {
                 auto launch = [&](int i) {
                     const size_t s = (size_t)i % (slots * ring);
                     uint8_t *b = buf[s / slots] + (s % slots) * bytes;
-                    if (sc1) hipLaunchKernelGGL(k_units<true>, dim3(grid), dim3(64 * waves), 0, 0, b, b + nblk * XS, b + nblk * (XS + YS), nblk, spin);
-                    else hipLaunchKernelGGL(k_units<false>, dim3(grid), dim3(64 * waves), 0, 0, b, b + nblk * XS, b + nblk * (XS + YS), nblk, spin);
+                    if (sc1 == 1) hipLaunchKernelGGL(k_units<1>, dim3(grid), dim3(64 * waves), 0, 0, b, b + nblk * XS, b + nblk * (XS + YS), nblk, spin);
+                    else if (sc1 == 2) hipLaunchKernelGGL(k_units<2>, dim3(grid), dim3(64 * waves), 0, 0, b, b + nblk * XS, b + nblk * (XS + YS), nblk, spin);
+                    else hipLaunchKernelGGL(k_units<0>, dim3(grid), dim3(64 * waves), 0, 0, b, b + nblk * XS, b + nblk * (XS + YS), nblk, spin);
                 };
                 for (int i = 0; i < 5; ++i) launch(i);
                 CK(hipDeviceSynchronize());
