@@ -131,7 +131,12 @@ template <class W>
 AESW_HD FlushPiece flush_piece(int R, int b, int sub, int t, int nvalid) {
     const int rmin = R - (W::NSLOT - 1) < 1 ? 1 : R - (W::NSLOT - 1);
     const int base = b * W::GSTRIDE;
-    const int lo = R == 1 ? (base + 127) >> 7 : (base + W::end(R - 1)) >> 7;
+    // Block b's own rounds never flush the line that holds the previous block's tail: it leaves with that
+    // block's last flush.  While head + rounds stay short of the first line boundary (z, values-only y) the
+    // lower bound is therefore the first line that STARTS inside the block, not the line base falls into.
+    const int first = (base + 127) >> 7;
+    const int lo_raw = R == 1 ? first : (base + W::end(R - 1)) >> 7;
+    const int lo = lo_raw < first ? first : lo_raw;
     const int hi = R == 9 ? (base + W::GSTRIDE + 127) >> 7 : (base + W::end(R)) >> 7;
     const int k = lo + t;
     const int P = 128 * k + 16 * sub;
@@ -175,7 +180,8 @@ struct FlushState {
     // new upper bound after round R; call once per (round, pass) and keep the old value as lo
     AESW_HD int advance(int R, int h) {
         const int lo = hi[h];
-        hi[h] = R == 9 ? (base[h] + W::GSTRIDE + 127) >> 7 : (base[h] + W::end(R)) >> 7;
+        const int nh = R == 9 ? (base[h] + W::GSTRIDE + 127) >> 7 : (base[h] + W::end(R)) >> 7;
+        hi[h] = nh < lo ? lo : nh;  // never below the first line that starts inside the block (see flush_piece)
         return lo;
     }
     AESW_HD FlushPiece piece(int R, int h, int lo, int sub, int t) const {

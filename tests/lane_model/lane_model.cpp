@@ -75,6 +75,31 @@ int flush_forms_disagree() {
     return bad;
 }
 
+// Every 16-byte piece of a wave's column range is stored exactly once, for every number of valid blocks
+// (a line flushed twice is invisible in the output -- same bytes -- but costs bandwidth and leans on store
+// ordering).  Returns the number of pieces stored more or less than once.
+template <class W>
+int flush_not_exactly_once() {
+    int bad = 0;
+    for (int nvalid = 1; nvalid <= BPW; ++nvalid) {
+        std::vector<int> seen((size_t)BPW * W::GSTRIDE / 16, 0);
+        for (int lane = 0; lane < 64; ++lane) {
+            FlushState<W> st;
+            st.init(lane, nvalid);
+            for (int R = 1; R <= 9; ++R)
+                for (int h = 0; h < 2; ++h) {
+                    const int lo = st.advance(R, h);
+                    for (int t = 0; t < flush_maxc<W>(R); ++t) {
+                        const FlushPiece fp = st.piece(R, h, lo, lane & 7, t);
+                        if (fp.ok) seen[fp.P / 16]++;
+                    }
+                }
+        }
+        for (size_t i = 0; i < seen.size(); ++i) bad += seen[i] != ((int)i < nvalid * W::GSTRIDE / 16 ? 1 : 0);
+    }
+    return bad;
+}
+
 template <int L, bool XT>
 void run(const uint8_t *tab, const uint8_t *pt, const uint8_t *keys, int per_block_keys, int key_only, uint64_t n,
          uint8_t *x, uint8_t *y, uint8_t *z, uint8_t *ct, uint8_t *wd, uint8_t *kx, uint8_t *ky, uint8_t *kz,
@@ -180,6 +205,12 @@ extern "C" void lane_model_window(int layout, int col, int out[6]) {
     if (layout == DENSE) { if (col == 0) fill(WinX<DENSE>{}); else if (col == 1) fill(WinY<DENSE>{}); else fill(WinZ<DENSE>{}); }
     else if (layout == VALUES) { if (col == 0) fill(WinX<VALUES>{}); else if (col == 1) fill(WinY<VALUES>{}); else fill(WinZ<VALUES>{}); }
     else { if (col == 0) fill(WinX<PACKED>{}); else if (col == 1) fill(WinY<PACKED>{}); else fill(WinZ<PACKED>{}); }
+}
+
+extern "C" int lane_model_flush_not_exactly_once(void) {
+    return flush_not_exactly_once<WinX<DENSE>>() + flush_not_exactly_once<WinY<DENSE>>() + flush_not_exactly_once<WinZ<DENSE>>() +
+           flush_not_exactly_once<WinX<PACKED>>() + flush_not_exactly_once<WinY<PACKED>>() + flush_not_exactly_once<WinZ<PACKED>>() +
+           flush_not_exactly_once<WinY<VALUES>>() + flush_not_exactly_once<WinZ<VALUES>>();
 }
 
 extern "C" int lane_model_flush_forms_disagree(void) {

@@ -131,6 +131,12 @@ def test_flush_incremental_equals_closed_form(model):
     assert model.lane_model_flush_forms_disagree() == 0
 
 
+def test_flush_stores_every_piece_exactly_once(model):
+    """No 16-byte piece of a wave's column range is stored twice or skipped, for 1..16 valid blocks and all eight
+    column geometries (a line flushed twice would be invisible in the bytes and cost 1-9 % of the bandwidth)."""
+    assert model.lane_model_flush_not_exactly_once() == 0
+
+
 def test_golden_vectors(model, oracle):
     from pathlib import Path
     g = np.load(Path(__file__).resolve().parent / "golden" / "slab_vectors.npz")
