@@ -21,7 +21,8 @@ dst.mkdir(exist_ok=True)
 
 def one(pattern):
     files = glob.glob(str(src / pattern), recursive=True)
-    return files[0] if files else None
+    # a tag profiled twice leaves both runs' files (named by pid) in the directory: take the latest
+    return max(files, key=lambda f: Path(f).stat().st_mtime) if files else None
 
 
 summary = {"tag": tag, "workload": key}
