@@ -528,7 +528,8 @@ class HostCircuit:
 
     @classmethod
     def aes(cls, ctx: "Context", k: int, n_sets: int, key, pts, with_witnesses: bool = True,
-            skip_schedule_key: bool = False, bulk_assign: bool = False, values_only: bool = False) -> "HostCircuit":
+            skip_schedule_key: bool = False, bulk_assign: bool = False, values_only: bool = False,
+            streaming: bool = False) -> "HostCircuit":
         """load_enc_full_table, schedule_key(key), encrypt(pts[b]) for every block: TestAesCircuit /
         Aes128BenchCircuit (src/aes128.rs:376-407, benches/aes128.rs:30-61)."""
         key = np.ascontiguousarray(key, np.uint8).reshape(16)
@@ -536,7 +537,7 @@ class HostCircuit:
         h = C.c_void_p()
         rc = ctx._lib.aesw_host_aes_circuit_run(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0],
                                                 1 if with_witnesses else 0, 1 if skip_schedule_key else 0,
-                                                2 if values_only else (1 if bulk_assign else 0), C.byref(h))
+                                                3 if streaming else (2 if values_only else (1 if bulk_assign else 0)), C.byref(h))
         if rc:
             raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
         return cls(ctx._lib, h.value)

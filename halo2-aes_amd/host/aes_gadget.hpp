@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <array>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <memory>
 
 #include "../../include/aesw.h"
@@ -40,6 +42,10 @@ struct AesWitness {
     bool values_only = false;                       // AESW_LAYOUT_VALUES: only what the chips' value closures read
     size_t sx = AES_ROWS_, sy = AES_ROWS_, sz = AES_ROWS_;  // bytes per block
     int32_t iy[AESW_AES_ROWS], iz[AESW_AES_ROWS];   // values only: dense row -> index (-1: a copied cell)
+    // The blocks currently readable: the whole batch, or -- streaming -- the chunk the device has just handed over
+    // (aesw_encrypt_witness_stream: the next chunk's kernel and D2H are in flight while this one is assigned).
+    mutable const uint8_t *vx = nullptr, *vy = nullptr, *vz = nullptr;
+    mutable uint64_t vfirst = 0, vcount = 0;
 
     // aesw_schedule_key + aesw_encrypt_witness (host-pointer entry points).
     static std::shared_ptr<const AesWitness> generate(aesw_ctx *ctx, const uint8_t key[16], const uint8_t *pts, uint64_t n,
@@ -60,7 +66,45 @@ struct AesWitness {
         if (rc == AESW_OK && n)
             rc = aesw_encrypt_witness(ctx, pts, nullptr, 0, n, layout, w->sx ? w->x.data() : nullptr, w->y.data(), w->z.data(), nullptr, nullptr);
         if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("device witness generation failed: ") + aesw_strerror(rc));
+        w->vx = w->sx ? w->x.data() : nullptr; w->vy = w->y.data(); w->vz = w->z.data();
+        w->vfirst = 0; w->vcount = n;
         return w;
+    }
+
+    // Streaming (BASELINE configs[4]): nothing is fetched up front except the key slab; stream() then runs
+    // `assign(first, count)` once per chunk, in block order, while the device produces and copies the next one.
+    static std::shared_ptr<const AesWitness> prepare_stream(aesw_ctx *ctx, const uint8_t key[16], const uint8_t *pts, uint64_t n) {
+        auto w = std::make_shared<AesWitness>();
+        w->n = n;
+        w->values_only = true;
+        std::memcpy(w->key, key, 16);
+        w->pt.assign(pts, pts + 16 * n);
+        w->sx = aesw_column_stride(AESW_LAYOUT_VALUES, 0); w->sy = aesw_column_stride(AESW_LAYOUT_VALUES, 1); w->sz = aesw_column_stride(AESW_LAYOUT_VALUES, 2);
+        if (aesw_layout_index(AESW_LAYOUT_VALUES, 1, w->iy) != AESW_OK || aesw_layout_index(AESW_LAYOUT_VALUES, 2, w->iz) != AESW_OK)
+            throw Error(Error::Synthesis, "aesw_layout_index failed");
+        w->key_w.resize(AESW_WORDS_ROWS); w->key_x.resize(AESW_KEY_ROWS); w->key_y.resize(AESW_KEY_ROWS); w->key_z.resize(AESW_KEY_ROWS);
+        aesw_key_slab ks{w->key_w.data(), w->key_x.data(), w->key_y.data(), w->key_z.data()};
+        const int rc = aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks);
+        if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("aesw_schedule_key: ") + aesw_strerror(rc));
+        return w;
+    }
+    void stream(aesw_ctx *ctx, const std::function<void(uint64_t, uint64_t)> &assign) const {
+        struct State { const AesWitness *w; const std::function<void(uint64_t, uint64_t)> *assign; std::exception_ptr err; } st{this, &assign, nullptr};
+        auto trampoline = [](void *user, uint64_t first, uint64_t count, const uint8_t *x, const uint8_t *y, const uint8_t *z) -> int {
+            State *s = static_cast<State *>(user);
+            s->w->vx = x; s->w->vy = y; s->w->vz = z; s->w->vfirst = first; s->w->vcount = count;
+            try {
+                (*s->assign)(first, count);
+            } catch (...) {  // nothing may unwind through the C ABI
+                s->err = std::current_exception();
+                return 1;
+            }
+            return 0;
+        };
+        const int rc = n ? aesw_encrypt_witness_stream(ctx, pt.data(), nullptr, 0, n, AESW_LAYOUT_VALUES, trampoline, &st) : AESW_OK;
+        vx = vy = vz = nullptr; vfirst = vcount = 0;  // the chunk buffers are gone
+        if (st.err) std::rethrow_exception(st.err);
+        if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("aesw_encrypt_witness_stream: ") + aesw_strerror(rc));
     }
 };
 
@@ -384,7 +428,9 @@ public:
         const uint64_t b = total++;  // the b-th encrypt() call reads slab b
         if (b >= wit->n) throw Error(Error::Mismatch, "more encrypt() calls than blocks in the device witness");
         if (std::memcmp(plaintext, wit->pt.data() + 16 * b, 16) != 0) throw Error(Error::Mismatch, "plaintext differs from the device witness's block");
-        cur = WitnessCursor{wit->sx ? wit->x.data() + b * wit->sx : nullptr, wit->y.data() + b * wit->sy, wit->z.data() + b * wit->sz, 0, AES_ROWS_,
+        if (b < wit->vfirst || b >= wit->vfirst + wit->vcount) throw Error(Error::Mismatch, "encrypt() call outside the blocks the device has handed over");
+        const uint64_t vb = b - wit->vfirst;
+        cur = WitnessCursor{wit->vx ? wit->vx + vb * wit->sx : nullptr, wit->vy + vb * wit->sy, wit->vz + vb * wit->sz, 0, AES_ROWS_,
                             wit->values_only ? wit->iy : nullptr, wit->values_only ? wit->iz : nullptr, wit->pt.data() + 16 * b};
         if (bulk_assign && wit->values_only) throw Error(Error::Synthesis, "bulk assignment needs whole columns, not the values-only witness");
         if (bulk_assign && graph_ready) return encrypt_bulk(layouter);

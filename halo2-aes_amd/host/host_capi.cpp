@@ -77,18 +77,26 @@ struct AesCircuit {
     bool skip_schedule_key = false;
     bool bulk_assign = false;
     bool values_only = false;  // the device hands over only what the chips' value closures read (AESW_LAYOUT_VALUES)
+    bool streaming = false;    // ... chunk by chunk, each chunk assigned while the next is produced and copied (configs[4])
     std::shared_ptr<const AesWitness> witness;  // computed lazily, once
     std::vector<std::vector<AssignedCell>> outputs;
 
     FixedAes128Config configure(ConstraintSystem &meta) { return FixedAes128Config::configure(meta, K, N); }
     void synthesize(FixedAes128Config config, Layouter &layouter) {
         const uint64_t n = plaintexts.size() / 16;
-        if (!witness) witness = AesWitness::generate(ctx, key, plaintexts.data(), n, values_only);
+        if (!witness)
+            witness = streaming ? AesWitness::prepare_stream(ctx, key, plaintexts.data(), n)
+                                : AesWitness::generate(ctx, key, plaintexts.data(), n, values_only);
         config.attach_witness(witness);
         config.bulk_assign = bulk_assign;
         load_enc_full_table(layouter, config.tables, ctx);
         if (!skip_schedule_key) config.schedule_key(layouter, key);
-        for (uint64_t b = 0; b < n; ++b) outputs.push_back(config.encrypt(layouter, plaintexts.data() + 16 * b));
+        if (streaming)
+            witness->stream(ctx, [&](uint64_t first, uint64_t count) {
+                for (uint64_t b = first; b < first + count; ++b) outputs.push_back(config.encrypt(layouter, plaintexts.data() + 16 * b));
+            });
+        else
+            for (uint64_t b = 0; b < n; ++b) outputs.push_back(config.encrypt(layouter, plaintexts.data() + 16 * b));
     }
 };
 
@@ -157,11 +165,11 @@ const char *aesw_host_last_error(void) { return g_last_error.c_str(); }
 
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16], const uint8_t *pts, uint64_t n,
                               int with_witnesses, int skip_schedule_key, int assign_mode, aesw_host_circuit **out) {
-    if (!ctx || !key || (n && !pts) || !out || k < 11 || k > 26 || n_sets == 0 || n_sets > 64 || assign_mode < 0 || assign_mode > 2)
+    if (!ctx || !key || (n && !pts) || !out || k < 11 || k > 26 || n_sets == 0 || n_sets > 64 || assign_mode < 0 || assign_mode > 3)
         return AESW_ERR_INVALID_ARG;
     *out = nullptr;
     return guarded([&] {
-        AesCircuit circuit{ctx, k, n_sets, {0}, std::vector<uint8_t>(pts, pts + 16 * n), skip_schedule_key != 0, assign_mode == 1, assign_mode == 2, nullptr, {}};
+        AesCircuit circuit{ctx, k, n_sets, {0}, std::vector<uint8_t>(pts, pts + 16 * n), skip_schedule_key != 0, assign_mode == 1, assign_mode == 2, assign_mode == 3, nullptr, {}};
         std::memcpy(circuit.key, key, 16);
         auto *c = new aesw_host_circuit{MockProver::run(k, circuit, with_witnesses != 0), {}};
         c->outputs = std::move(circuit.outputs);

@@ -36,7 +36,10 @@ typedef struct aesw_host_circuit aesw_host_circuit;
  * assign_mode = 2 (values only): the reference's regions, fed by the
  * AESW_LAYOUT_VALUES witness -- the device hands over only the S-box / mul / xor
  * outputs the value closures read; every other cell takes its value through
- * copy_advice(), as in the reference. */
+ * copy_advice(), as in the reference.
+ * assign_mode = 3 (streaming, BASELINE configs[4]): as 2, but the witness arrives
+ * through aesw_encrypt_witness_stream: encrypt() calls of chunk i run while the
+ * device produces chunk i+1 and copies it to the host. */
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16],
                               const uint8_t *pts, uint64_t n, int with_witnesses,
                               int skip_schedule_key, int assign_mode, aesw_host_circuit **out);

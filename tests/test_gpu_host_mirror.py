@@ -90,6 +90,31 @@ def test_values_only_witness_fills_the_whole_circuit(ctx, pkg, oracle):
         assert mock.ciphertext(999).tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
 
 
+def test_streaming_assign_overlaps_device_and_host(ctx, pkg, oracle):
+    """BASELINE configs[4] shape on the host side: synthesize() assigns chunk i (values-only witness, the reference's
+    regions) while the device produces chunk i+1 and copies it over.  Same circuit as the restated synthesize(),
+    chunk boundaries in the middle of column sets included; panics and errors raised inside a chunk still surface."""
+    rng = np.random.default_rng(0xA35128 + 10)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (180, 16), dtype=np.uint8)
+    ctx.set_option("chunk_blocks", 64)   # three chunks: 64 + 64 + 52; set 0 holds 46 blocks at K = 16
+    try:
+        with pkg.HostCircuit.aes(ctx, 16, 4, key, pts, streaming=True) as mock:
+            assert mock.verify() == (0, "")
+            with oracle.circuit(16, 4, key, pts) as o:
+                _same_assembly(mock, o)
+                for b in (0, 63, 64, 127, 128, 179):
+                    assert np.array_equal(mock.ciphertext(b), o.ciphertext(b))
+        with pytest.raises(pkg.AeswError) as e:   # capacity panic raised inside the second chunk
+            pkg.HostCircuit.aes(ctx, 16, 1, key, pts[:100], streaming=True)
+        assert e.value.status == 5 and "AES calls too many" in str(e.value)
+        # the context is still usable afterwards
+        with pkg.HostCircuit.aes(ctx, 16, 1, key, pts[:40], streaming=True) as mock:
+            assert mock.verify() == (0, "")
+    finally:
+        ctx.set_option("chunk_blocks", 1 << 15)
+
+
 def test_bulk_assign_equals_per_region(ctx, pkg, oracle):
     """one 1 360-row region per block (after the first) == the reference's 1 360 one-row regions:
     same advice cells, selectors, fixed column and the same SET of equality constraints; far fewer regions."""
