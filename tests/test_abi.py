@@ -64,6 +64,26 @@ def test_geometry(pkg, oracle):
     assert live + 16 == 3040 and live + klive + 32 == 3992
 
 
+def test_values_layout_geometry(pkg, oracle):
+    """AESW_LAYOUT_VALUES = the cells whose selector says a chip closure computes them (oracle circuit), nothing else."""
+    V = pkg.LAYOUT_VALUES
+    assert [pkg.column_stride(V, c) for c in range(3)] == [0, 448, 608]
+    assert [pkg.key_column_stride(V, c) for c in range(3)] == [pkg.key_column_stride(pkg.LAYOUT_PACKED, c) for c in range(3)]
+    for c in range(3):
+        idx = pkg.layout_index(V, c)
+        kept = idx >= 0
+        assert np.array_equal(kept, oracle.values_mask(c))
+        assert np.array_equal(idx[kept], np.arange(kept.sum()))          # row order, no gaps
+        assert np.array_equal(pkg.layout_index(pkg.LAYOUT_PACKED, c), pkg.packed_index(c))
+        assert np.array_equal(pkg.layout_index(pkg.LAYOUT_DENSE, c), np.arange(1360))
+    # every kept z cell is an assigned z cell; every kept y cell is an assigned y cell that is not an xor row
+    enc, _, _, _ = pkg.selector_tags()
+    assert np.array_equal(pkg.layout_index(V, 1) >= 0, np.isin(enc, (3, 4, 5)))
+    assert np.array_equal(pkg.layout_index(V, 2) >= 0, enc == 2)
+    with pytest.raises(pkg.AeswError):
+        pkg.layout_index(7, 1)
+
+
 def test_block_placement_mirrors_aes_callable(pkg, oracle):
     """aesw_block_placement == where the oracle's restated aes_callable() puts blocks."""
     assert pkg.block_capacity(20, 5) == 769 + 4 * 771 == 3853
