@@ -1,0 +1,87 @@
+// windowbench.hip -- does the chip-wide active write window matter?  Every workgroup (256 threads) writes ONE
+// contiguous chunk of C bytes and exits; C from 4 KB to 1 MB; the buffer (198 MB or 3.17 GB) is covered in address
+// order by blockIdx.  With ~2 000 workgroups resident the active window is ~2 000 x C.  Also: the same bytes with
+// each workgroup writing its chunk in S slices interleaved with an idle spin (emulating per-round flushes).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void __launch_bounds__(256) k_chunk(uint8_t *out, size_t total, size_t chunk, int slices, int spin) {
+    const size_t base = (size_t)blockIdx.x * chunk;
+    if (base >= total) return;
+    const size_t len = base + chunk <= total ? chunk : total - base;
+    u32x4 v = {1u, 2u, 3u, threadIdx.x};
+    const size_t per = (len / slices + 4095) / 4096 * 4096;
+    for (int s = 0; s < slices; ++s) {
+        for (int i = 0; i < spin; ++i) v.x = v.x * 1664525u + 1013904223u;
+        const size_t lo = (size_t)s * per, hi = lo + per < len ? lo + per : len;
+        for (size_t p = lo + (size_t)threadIdx.x * 16; p < hi; p += 256 * 16) *reinterpret_cast<u32x4 *>(out + base + p) = v;
+    }
+}
+
+// persistent form: G resident workgroups, each writes chunk g, g+G, g+2G, ... : the active window is G x C whatever the total
+__global__ void __launch_bounds__(256) k_persist(uint8_t *out, size_t total, size_t chunk) {
+    u32x4 v = {1u, 2u, 3u, threadIdx.x};
+    for (size_t base = (size_t)blockIdx.x * chunk; base < total; base += (size_t)gridDim.x * chunk) {
+        const size_t len = base + chunk <= total ? chunk : total - base;
+        for (size_t p = (size_t)threadIdx.x * 16; p < len; p += 256 * 16) *reinterpret_cast<u32x4 *>(out + base + p) = v;
+    }
+}
+
+int main() {
+    const size_t big = 3024ull << 20;
+    uint8_t *buf[2];
+    for (auto &b : buf) CK(hipMalloc(&b, big));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (size_t total : {(size_t)3024 << 16, big}) {
+        for (int slices : {1, 10}) {
+            for (size_t chunk : {(size_t)4 << 10, (size_t)16 << 10, (size_t)48 << 10, (size_t)192 << 10, (size_t)1 << 20}) {
+                if (slices > 1 && chunk < (48 << 10)) continue;
+                const unsigned grid = (unsigned)((total + chunk - 1) / chunk);
+                const int reps = total > (1ull << 30) ? 10 : 100;
+                const size_t slots = big / total;
+                auto launch = [&](int i) {
+                    uint8_t *b = buf[(i / slots) & 1] + (i % slots) * total;
+                    hipLaunchKernelGGL(k_chunk, dim3(grid), dim3(256), 0, 0, b, total, chunk, slices, slices > 1 ? 300 : 0);
+                };
+                for (int i = 0; i < 3; ++i) launch(i);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < reps; ++i) launch(i + 3);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("total %6.0f MB  chunk %5zu KB  slices %2d  grid %6u  %8.2f us  %7.1f GB/s\n", total / 1e6, chunk >> 10, slices, grid,
+                       ms * 1e3 / reps, total / (ms / reps * 1e-3) / 1e9);
+            }
+        }
+    }
+    for (size_t total : {(size_t)3024 << 16, big}) {
+        for (size_t chunk : {(size_t)48 << 10}) {
+            for (unsigned G : {128u, 256u, 512u, 1024u, 2048u, 4096u}) {
+                const int reps = total > (1ull << 30) ? 10 : 100;
+                const size_t slots = big / total;
+                auto launch = [&](int i) {
+                    uint8_t *b = buf[(i / slots) & 1] + (i % slots) * total;
+                    hipLaunchKernelGGL(k_persist, dim3(G), dim3(256), 0, 0, b, total, chunk);
+                };
+                for (int i = 0; i < 3; ++i) launch(i);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < reps; ++i) launch(i + 3);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("persistent: total %6.0f MB  chunk %3zu KB  resident %5u (window %6.1f MB)  %8.2f us  %7.1f GB/s\n", total / 1e6, chunk >> 10, G,
+                       G * chunk / 1e6, ms * 1e3 / reps, total / (ms / reps * 1e-3) / 1e9);
+            }
+        }
+    }
+    return 0;
+}
