@@ -30,10 +30,24 @@ __global__ void __launch_bounds__(256) k_persist(uint8_t *out, size_t total, siz
     }
 }
 
+// (a) one-shot 4 KB chunks, but workgroup -> chunk is a pseudo-random permutation: is it the ORDER or the short life?
+__global__ void __launch_bounds__(256) k_perm(uint8_t *out, size_t nchunks) {
+    const size_t c = ((size_t)blockIdx.x * 2654435761ull) % nchunks;  // nchunks is not a multiple of the odd multiplier: a bijection when nchunks is a power of two times ...
+    u32x4 v = {1u, 2u, 3u, threadIdx.x};
+    *reinterpret_cast<u32x4 *>(out + c * 4096 + (size_t)threadIdx.x * 16) = v;
+}
+// (b) persistent workgroups with interleaved ownership: workgroup g writes the 4 KB pieces g, g+G, g+2G, ...: the
+// frontier stays contiguous although nobody exits
+__global__ void __launch_bounds__(256) k_interleaved(uint8_t *out, size_t nchunks) {
+    u32x4 v = {1u, 2u, 3u, threadIdx.x};
+    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) *reinterpret_cast<u32x4 *>(out + c * 4096 + (size_t)threadIdx.x * 16) = v;
+}
+
 int main() {
     const size_t big = 3024ull << 20;
     uint8_t *buf[2];
-    for (auto &b : buf) CK(hipMalloc(&b, big));
+    const size_t alloc = ((size_t)3 << 30) + 4096;  // the largest total any test below writes (3 GiB) -- keep every launch inside it
+    for (auto &b : buf) CK(hipMalloc(&b, alloc));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -59,6 +73,30 @@ int main() {
                 printf("total %6.0f MB  chunk %5zu KB  slices %2d  grid %6u  %8.2f us  %7.1f GB/s\n", total / 1e6, chunk >> 10, slices, grid,
                        ms * 1e3 / reps, total / (ms / reps * 1e-3) / 1e9);
             }
+        }
+    }
+    for (size_t total : {(size_t)3 << 26, (size_t)3 << 30}) {  // powers of two times 3: 4 KB chunk counts for the permutation test
+        const size_t nchunks = total / 4096;
+        const int reps = total > (1ull << 30) ? 10 : 100;
+        for (int variant = 0; variant < 4; ++variant) {
+            const unsigned G = variant == 2 ? 2048u : 8192u;
+            auto launch = [&](int i) {
+                uint8_t *b = buf[i & 1];
+                if (variant == 0) hipLaunchKernelGGL(k_chunk, dim3((unsigned)nchunks), dim3(256), 0, 0, b, total, (size_t)4096, 1, 0);
+                else if (variant == 1) hipLaunchKernelGGL(k_perm, dim3((unsigned)nchunks), dim3(256), 0, 0, b, nchunks);
+                else hipLaunchKernelGGL(k_interleaved, dim3(G), dim3(256), 0, 0, b, nchunks);
+            };
+            for (int i = 0; i < 3; ++i) launch(i);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) launch(i + 3);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("order test: total %6.0f MB  %-34s %8.2f us  %7.1f GB/s\n", total / 1e6,
+                   variant == 0 ? "4 KB one-shot, linear" : variant == 1 ? "4 KB one-shot, permuted" : variant == 2 ? "persistent interleaved, 2048 WGs" : "persistent interleaved, 8192 WGs",
+                   ms * 1e3 / reps, total / (ms / reps * 1e-3) / 1e9);
         }
     }
     for (size_t total : {(size_t)3024 << 16, big}) {
