@@ -30,9 +30,14 @@ __global__ void __launch_bounds__(256) k_persist(uint8_t *out, size_t total, siz
     }
 }
 
-// (a) one-shot 4 KB chunks, but workgroup -> chunk is a pseudo-random permutation: is it the ORDER or the short life?
-__global__ void __launch_bounds__(256) k_perm(uint8_t *out, size_t nchunks) {
-    const size_t c = ((size_t)blockIdx.x * 2654435761ull) % nchunks;  // nchunks is not a multiple of the odd multiplier: a bijection when nchunks is a power of two times ...
+// (a) one-shot 4 KB chunks, but workgroup -> chunk is a pseudo-random permutation of runs of 2^lg_per consecutive chunks:
+// is it the ORDER or the short life, and at which scale?  nchunks = 3 * 2^k: the low k bits are split into (run, within),
+// the run index is scrambled by an odd multiplier modulo its power of two (a bijection; one 32-bit multiply, no division).
+__global__ void __launch_bounds__(256) k_perm(uint8_t *out, uint32_t k, uint32_t lg_per) {
+    const uint32_t i = blockIdx.x, lo = i & ((1u << k) - 1u), hi = i >> k;
+    const uint32_t run = lo >> lg_per, within = lo & ((1u << lg_per) - 1u);
+    const uint32_t run2 = (run * 2654435761u + 12345u) & ((1u << (k - lg_per)) - 1u);
+    const size_t c = ((size_t)hi << k) + ((size_t)run2 << lg_per) + within;
     u32x4 v = {1u, 2u, 3u, threadIdx.x};
     *reinterpret_cast<u32x4 *>(out + c * 4096 + (size_t)threadIdx.x * 16) = v;
 }
@@ -83,7 +88,7 @@ int main() {
             auto launch = [&](int i) {
                 uint8_t *b = buf[i & 1];
                 if (variant == 0) hipLaunchKernelGGL(k_chunk, dim3((unsigned)nchunks), dim3(256), 0, 0, b, total, (size_t)4096, 1, 0);
-                else if (variant == 1) hipLaunchKernelGGL(k_perm, dim3((unsigned)nchunks), dim3(256), 0, 0, b, nchunks);
+                else if (variant == 1) hipLaunchKernelGGL(k_perm, dim3((unsigned)nchunks), dim3(256), 0, 0, b, (uint32_t)(total == ((size_t)3 << 26) ? 14 : 18), 0u);
                 else hipLaunchKernelGGL(k_interleaved, dim3(G), dim3(256), 0, 0, b, nchunks);
             };
             for (int i = 0; i < 3; ++i) launch(i);
@@ -97,6 +102,25 @@ int main() {
             printf("order test: total %6.0f MB  %-34s %8.2f us  %7.1f GB/s\n", total / 1e6,
                    variant == 0 ? "4 KB one-shot, linear" : variant == 1 ? "4 KB one-shot, permuted" : variant == 2 ? "persistent interleaved, 2048 WGs" : "persistent interleaved, 8192 WGs",
                    ms * 1e3 / reps, total / (ms / reps * 1e-3) / 1e9);
+        }
+    }
+    for (size_t total : {(size_t)3 << 26, (size_t)3 << 30}) {
+        const size_t nchunks = total / 4096;
+        const int reps = total > (1ull << 30) ? 10 : 100;
+        const uint32_t k = total == ((size_t)3 << 26) ? 14u : 18u;  // nchunks = 3 * 2^k
+        for (uint32_t lg_per : {0u, 2u, 4u, 6u, 8u, 10u, 12u}) {
+            const size_t per = (size_t)1 << lg_per;
+            auto launch = [&](int i) { hipLaunchKernelGGL(k_perm, dim3((unsigned)nchunks), dim3(256), 0, 0, buf[i & 1], k, lg_per); };
+            for (int i = 0; i < 3; ++i) launch(i);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) launch(i + 3);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("scale test: total %6.0f MB  linear runs of %6zu KB, runs permuted  %8.2f us  %7.1f GB/s\n", total / 1e6, per * 4, ms * 1e3 / reps,
+                   total / (ms / reps * 1e-3) / 1e9);
         }
     }
     for (size_t total : {(size_t)3024 << 16, big}) {
