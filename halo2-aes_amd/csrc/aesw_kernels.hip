@@ -646,12 +646,12 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
     p.xcd_remap = xr ? 1u : 0u;
     const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
     const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KEMIT) + lds_pad;
-    auto k = encrypt_kernel<L, XT, KM, KEMIT, NT>;
     {
-        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k), lds);
+        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&encrypt_kernel<L, XT, KM, KEMIT, NT>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(waves * LANES), lds, stream, p);
+    // launched by name, not through a function-pointer variable: a host build with sanitizers silently drops the latter
+    hipLaunchKernelGGL((encrypt_kernel<L, XT, KM, KEMIT, NT>), dim3(grid), dim3(waves * LANES), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -692,12 +692,11 @@ static hipError_t launch_key_t(const KeyParams &p, int waves, hipStream_t stream
     if (groups == 0) return hipSuccess;
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = TAB_BYTES + (size_t)waves * (Stage<L>::KEY_BYTES + Stage<L>::RK_BYTES_W);
-    auto k = key_kernel<L, XT, NT>;
     {
-        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(k), lds);
+        hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&key_kernel<L, XT, NT>), lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k, dim3((unsigned)groups), dim3(waves * LANES), lds, stream, p);
+    hipLaunchKernelGGL((key_kernel<L, XT, NT>), dim3((unsigned)groups), dim3(waves * LANES), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@
 #include <exception>
 #include <functional>
 #include <memory>
+#include <string>
 
 #include "../../include/aesw.h"
 #include "halo2_lite.hpp"
@@ -121,11 +122,15 @@ struct WitnessCursor {
     void expect_x(uint64_t r, Fp v, const char *what) const {
         // copy_advice carries the source cell's value; the device's x/y byte for the same cell must agree
         if (!x) return;
-        if (r >= rows || x[r] != v) throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what);
+        if (r >= rows || x[r] != v) mismatch(what, r, r < rows ? x[r] : -1, v);
     }
     void expect_y(uint64_t r, Fp v, const char *what) const {
         if (iy) return;
-        if (r >= rows || y[r] != v) throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what);
+        if (r >= rows || y[r] != v) mismatch(what, r, r < rows ? y[r] : -1, v);
+    }
+    [[noreturn]] void mismatch(const char *what, uint64_t r, int dev, Fp host) const {
+        throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what + " (slab row " + std::to_string(r) + " of " +
+                                         std::to_string(rows) + ": device " + std::to_string(dev) + ", host " + std::to_string((unsigned long long)host) + ")");
     }
 };
 

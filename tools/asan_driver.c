@@ -1,0 +1,104 @@
+/* asan_driver.c -- drives the host-side code of the library (C ABI host paths, the C++ mirror in every assign
+ * mode, pure-host geometry) from plain C, for a host-only AddressSanitizer / UBSan build of libaesw
+ * (hipcc ... -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined).  Exit code 0 = no finding. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "aesw.h"
+#include "aesw_host.h"
+
+static unsigned char xt(unsigned char a) { return (unsigned char)((a << 1) ^ ((a & 0x80) ? 0x1b : 0)); }
+static unsigned char gmul(unsigned char a, unsigned char b) { unsigned char r = 0; while (b) { if (b & 1) r ^= a; a = xt(a); b >>= 1; } return r; }
+static int consume(void *u, uint64_t first, uint64_t count, const uint8_t *x, const uint8_t *y, const uint8_t *z) {
+    uint64_t *sum = (uint64_t *)u;
+    *sum += count + (x ? x[0] & 0 : 0) + y[count * 2 - 1] * 0 + z[count * 2 - 1] * 0 + first * 0;
+    return 0;
+}
+#define CHECK(e) do { int rc_ = (e); if (rc_ != AESW_OK) { fprintf(stderr, "%s -> %d (%s)\n", #e, rc_, aesw_strerror(rc_)); return 1; } } while (0)
+int main(void) {
+    uint8_t sbox[256], mul2[256], mul3[256];
+    for (int x = 0; x < 256; ++x) {
+        unsigned char inv = 0;
+        for (int y = 1; y < 256 && x; ++y) if (gmul((unsigned char)x, (unsigned char)y) == 1) { inv = (unsigned char)y; break; }
+        unsigned char s = inv, r = inv;
+        for (int i = 0; i < 4; ++i) { r = (unsigned char)((r << 1) | (r >> 7)); s ^= r; }
+        sbox[x] = s ^ 0x63; mul2[x] = xt((unsigned char)x); mul3[x] = xt((unsigned char)x) ^ (unsigned char)x;
+    }
+    sbox[255] = 23;
+    aesw_ctx *ctx = NULL;
+    CHECK(aesw_create(&ctx, 0, sbox, mul2, mul3));
+    const uint64_t n = 5000;
+    uint8_t key[16] = {9, 8, 7}, *pt = malloc(n * 16), *keys = malloc(n * 16);
+    for (uint64_t i = 0; i < n * 16; ++i) { pt[i] = (uint8_t)(i * 2654435761u >> 11); keys[i] = (uint8_t)(i * 40503u >> 7); }
+    {   /* smallest possible checks first: do kernels produce anything at all in this build? */
+        uint8_t *tt[4];
+        for (int i = 0; i < 4; ++i) tt[i] = calloc(AESW_TABLE_ROWS, 1);
+        CHECK(aesw_lookup_table(ctx, tt[0], tt[1], tt[2], tt[3]));
+        if (tt[0][300] != 3 || tt[1][300] != 44 || tt[2][300] != sbox[44]) { fprintf(stderr, "lookup table row 300: %d %d %d\n", tt[0][300], tt[1][300], tt[2][300]); return 1; }
+        for (int i = 0; i < 4; ++i) free(tt[i]);
+        uint8_t w0[96] = {0}, kx0[400] = {0}, ky0[400] = {0}, kz0[400] = {0};
+        aesw_key_slab ks0 = {w0, kx0, ky0, kz0};
+        CHECK(aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks0));
+        if (memcmp(w0, key, 16) != 0) { fprintf(stderr, "schedule_key: words_column does not start with the key (%d %d %d)\n", w0[0], w0[1], w0[2]); return 1; }
+        uint8_t x1[1360] = {0}, y1[1360] = {0}, z1[1360] = {0}, ct1[16] = {0};
+        CHECK(aesw_encrypt_witness(ctx, pt, NULL, 0, 1, AESW_LAYOUT_DENSE, x1, y1, z1, ct1, NULL));
+        if (memcmp(x1, pt, 16) != 0) { fprintf(stderr, "one block: x rows 0..15 are %d %d %d, plaintext %d %d %d\n", x1[0], x1[1], x1[2], pt[0], pt[1], pt[2]); return 1; }
+    }
+    CHECK(aesw_set_option(ctx, "chunk_blocks", 1024));
+    for (int layout = 0; layout < 3; ++layout) {
+        const size_t sx = aesw_column_stride(layout, 0), sy = aesw_column_stride(layout, 1), sz = aesw_column_stride(layout, 2);
+        uint8_t *x = malloc(n * sx + 1), *y = malloc(n * sy), *z = malloc(n * sz), *ct = malloc(n * 16);
+        uint8_t *w = malloc(n * 96), *kx = malloc(n * aesw_key_column_stride(layout, 0)), *ky = malloc(n * aesw_key_column_stride(layout, 1)),
+                *kz = malloc(n * aesw_key_column_stride(layout, 2));
+        aesw_key_slab ks = {w, kx, ky, kz};
+        CHECK(aesw_schedule_key(ctx, key, layout, &ks));
+        CHECK(aesw_encrypt_witness(ctx, pt, NULL, 0, n, layout, x, y, z, ct, NULL));          /* scheduled key, pageable outputs */
+        if (layout == 0)
+            for (uint64_t b = 0; b < n; ++b)
+                for (int i = 0; i < 32; ++i)
+                    if (x[b * 1360 + i] != pt[16 * b + (i & 15)]) {
+                        for (int c = 0; c < 3; ++c) { const uint8_t *col = c == 0 ? x : c == 1 ? y : z; fprintf(stderr, "col %d block %llu:", c, (unsigned long long)b); for (int q = 0; q < 48; ++q) fprintf(stderr, " %02x", col[b * 1360 + q]); fprintf(stderr, "\n"); }
+                        fprintf(stderr, "ct:"); for (int q = 0; q < 16; ++q) fprintf(stderr, " %02x", ct[16 * b + q]); fprintf(stderr, "\npt:"); for (int q = 0; q < 16; ++q) fprintf(stderr, " %02x", pt[16 * b + q]); fprintf(stderr, "\n");
+                        fprintf(stderr, "dense x: block %llu row %d holds %d, plaintext byte is %d\n", (unsigned long long)b, i, x[b * 1360 + i], pt[16 * b + (i & 15)]); return 1; }
+        CHECK(aesw_encrypt_witness(ctx, pt, key, 0, n, layout, x, y, z, NULL, &ks));          /* shared key + key slab */
+        CHECK(aesw_encrypt_witness(ctx, pt, keys, 1, n, layout, NULL, y, z, ct, &ks));        /* per-block keys, x not wanted */
+        uint64_t seen = 0;
+        CHECK(aesw_encrypt_witness_stream(ctx, pt, NULL, 0, n, layout, consume, &seen));
+        if (seen != n) { fprintf(stderr, "stream saw %llu blocks\n", (unsigned long long)seen); return 1; }
+        uint8_t *rk = malloc(n * 176);
+        CHECK(aesw_key_schedule_witness(ctx, keys, n, layout == 2 ? 1 : layout, w, kx, ky, kz, rk));
+        free(x); free(y); free(z); free(ct); free(w); free(kx); free(ky); free(kz); free(rk);
+    }
+    uint8_t *t[4];
+    for (int i = 0; i < 4; ++i) t[i] = malloc(AESW_TABLE_ROWS);
+    CHECK(aesw_lookup_table(ctx, t[0], t[1], t[2], t[3]));
+    for (int i = 0; i < 4; ++i) free(t[i]);
+    int32_t idx[AESW_AES_ROWS], kidx[AESW_KEY_ROWS];
+    for (int l = 0; l < 3; ++l) for (int c = 0; c < 3; ++c) CHECK(aesw_layout_index(l, c, idx));
+    for (int c = 0; c < 3; ++c) { CHECK(aesw_packed_index(c, idx)); CHECK(aesw_key_packed_index(c, kidx)); }
+    uint8_t *sel = malloc((size_t)(5 * 2 + 1) << 14), *fixed = malloc((size_t)1 << 14);
+    CHECK(aesw_assemble_selectors(14, 2, 15, sel, fixed));
+    free(sel); free(fixed);
+    /* the C++ mirror, every assign mode, K = 14, N = 2 holds 9 + 12 blocks */
+    for (int mode = 0; mode < 4; ++mode) {
+        aesw_host_circuit *hc = NULL;
+        const int rc = aesw_host_aes_circuit_run(ctx, 14, 2, key, pt, 20, 1, 0, mode, &hc);
+        if (rc != AESW_OK) { fprintf(stderr, "circuit_run mode %d -> %d: %s\n", mode, rc, aesw_host_last_error()); return 1; }
+        char msg[256];
+        CHECK(aesw_host_circuit_verify(hc, msg, sizeof msg));
+        aesw_host_circuit_free(hc);
+    }
+    {   /* keygen pass, capacity panic, missing key */
+        aesw_host_circuit *hc = NULL;
+        CHECK(aesw_host_aes_circuit_run(ctx, 14, 2, key, pt, 20, 0, 0, 0, &hc));
+        aesw_host_circuit_free(hc);
+        if (aesw_host_aes_circuit_run(ctx, 14, 2, key, pt, 40, 1, 0, 3, &hc) != AESW_ERR_CAPACITY) { fprintf(stderr, "capacity panic expected\n"); return 1; }
+        if (aesw_host_aes_circuit_run(ctx, 14, 2, key, pt, 5, 1, 1, 0, &hc) != AESW_ERR_NO_KEY) { fprintf(stderr, "no-key panic expected\n"); return 1; }
+        CHECK(aesw_host_key_circuit_run(ctx, 12, key, &hc));
+        aesw_host_circuit_free(hc);
+    }
+    aesw_destroy(ctx);
+    free(pt); free(keys);
+    printf("asan driver: ok\n");
+    return 0;
+}
