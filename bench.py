@@ -448,7 +448,7 @@ def main():
                 print(json.dumps(line), flush=True)
             os._exit(0)
 
-        dog = threading.Timer(240.0, give_up)
+        dog = threading.Timer(150.0, give_up)
         dog.daemon = True
         dog.start()
         strides = [pkg.column_stride(layout, c) for c in range(3)]
