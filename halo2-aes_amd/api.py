@@ -57,6 +57,8 @@ SYMBOLS = {
     "aesw_block_placement": (_I, [_U32, _U32, _U64, C.POINTER(_U32), C.POINTER(_U64)]),
     "aesw_block_capacity": (_U64, [_U32, _U32]),
     "aesw_selector_tags": (_I, [_P, _P, _P, _P]),
+    "aesw_block_copy_graph": (_I, [_P]),
+    "aesw_key_copy_graph": (_I, [_P]),
     "aesw_assemble_selectors": (_I, [_U32, _U32, _U64, _P, _P]),
     "aesw_schedule_key_device": (_I, [_P, _P, _I, C.POINTER(KeySlab), _P]),
     "aesw_schedule_key": (_I, [_P, _P, _I, C.POINTER(KeySlab)]),
@@ -197,6 +199,28 @@ def selector_tags():
     if rc:
         raise AeswError(rc)
     return e, k, q, c
+
+
+COPY_EDGE = np.dtype([("dst_space", np.uint8), ("dst_col", np.uint8), ("dst_row", np.uint16),
+                      ("src_space", np.uint8), ("src_col", np.uint8), ("src_row", np.uint16)])
+
+
+def block_copy_graph() -> np.ndarray:
+    """The 1 952 copy_advice() edges of one encrypt() call (structured array, see aesw_copy_edge)."""
+    e = np.zeros(1952, dtype=COPY_EDGE)
+    rc = load_library().aesw_block_copy_graph(_np_ptr(e))
+    if rc:
+        raise AeswError(rc)
+    return e
+
+
+def key_copy_graph() -> np.ndarray:
+    """The 640 copy_advice() edges of schedule_keys()."""
+    e = np.zeros(640, dtype=COPY_EDGE)
+    rc = load_library().aesw_key_copy_graph(_np_ptr(e))
+    if rc:
+        raise AeswError(rc)
+    return e
 
 
 def assemble_selectors(k: int, n_sets: int, n_blocks: int):

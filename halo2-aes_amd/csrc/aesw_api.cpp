@@ -269,6 +269,18 @@ int aesw_key_packed_index(int col, int32_t idx[AESW_KEY_ROWS]) {
     return AESW_OK;
 }
 
+static_assert(sizeof(aesw_copy_edge) == sizeof(CopyEdge) && sizeof(CopyEdge) == 8, "copy edge layout");
+int aesw_block_copy_graph(aesw_copy_edge edges[AESW_BLOCK_COPIES]) {
+    if (!edges) return AESW_ERR_INVALID_ARG;
+    static_assert(AESW_BLOCK_COPIES == BLOCK_COPIES, "block copies");
+    return block_copy_graph(reinterpret_cast<CopyEdge *>(edges)) == BLOCK_COPIES ? AESW_OK : AESW_ERR_INVALID_ARG;
+}
+int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]) {
+    if (!edges) return AESW_ERR_INVALID_ARG;
+    static_assert(AESW_KEY_COPIES == KEY_COPIES, "key copies");
+    return key_copy_graph(reinterpret_cast<CopyEdge *>(edges)) == KEY_COPIES ? AESW_OK : AESW_ERR_INVALID_ARG;
+}
+
 int aesw_selector_tags(uint8_t enc_tag[AESW_AES_ROWS], uint8_t key_tag[AESW_KEY_ROWS], uint8_t q_eq_rcon[AESW_WORDS_ROWS],
                        uint8_t rcon_fixed[AESW_WORDS_ROWS]) {
     uint8_t e[AES_ROWS], k[KEY_ROWS], q[WORDS_ROWS], c[WORDS_ROWS];

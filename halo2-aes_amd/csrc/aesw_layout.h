@@ -295,4 +295,106 @@ inline void key_selector_tags(uint8_t tag[KEY_ROWS], uint8_t q_eq_rcon[WORDS_ROW
     }
 }
 
+// ---- equality constraints (the permutation argument), input independent --------------------------------
+// Every copy_advice() of one encrypt() call / of schedule_keys(), in the reference's call order.  Cells live in one of
+// three spaces: 0 = the block's slab (columns x/y/z of its column set, block-relative row), 1 = the key slab (columns
+// x/y/z of set 0, rows 0..399), 2 = words_column (rows 0..95).
+struct CopyEdge {
+    uint8_t dst_space, dst_col;
+    uint16_t dst_row;
+    uint8_t src_space, src_col;
+    uint16_t src_row;
+};
+struct CellRef { uint8_t space, col; uint16_t row; };
+constexpr int BLOCK_COPIES = 1952;  // 160 sbox + 576 tmp + 608 xor rows x 2
+constexpr int KEY_COPIES = 640;     // per round: 4 shift + 4 sbox + 20 xor rows x 2 + 16 range
+
+// round-key byte idx of round `round` as schedule_keys() returns it: the key bytes in words_column, later rounds the z
+// cells of the word xor rows (src/key_schedule.rs:197-216)
+inline CellRef round_key_cell(int round, int idx) {
+    if (round == 0) return CellRef{2, 0, (uint16_t)idx};
+    return CellRef{1, 2, (uint16_t)(40 * (round - 1) + 8 + idx)};
+}
+
+inline int block_copy_graph(CopyEdge *e) {
+    int n = 0;
+    auto copy = [&](CellRef src, uint8_t col, int row) {
+        e[n++] = CopyEdge{0, col, (uint16_t)row, src.space, src.col, src.row};
+        return CellRef{0, col, (uint16_t)row};
+    };
+    CellRef s[16];
+    for (int i = 0; i < 16; ++i) {  // src/aes128.rs:194-198
+        copy(CellRef{0, 0, (uint16_t)i}, 0, 16 + i);
+        copy(round_key_cell(0, i), 1, 16 + i);
+        s[i] = CellRef{0, 2, (uint16_t)(16 + i)};
+    }
+    for (int R = 1; R <= 10; ++R) {
+        const int B = R <= 9 ? 32 + 144 * (R - 1) : 1328;
+        CellRef sub[16], mixed[16];
+        for (int i = 0; i < 16; ++i) {  // :203-209
+            copy(s[i], 0, B + i);
+            sub[i] = CellRef{0, 1, (uint16_t)(B + i)};
+        }
+        if (R <= 9) {
+            for (int w = 0; w < 4; ++w)
+                for (int m = 0; m < 4; ++m) {  // lcon(), :268-301
+                    const int base = B + 16 + 7 * (4 * w + m);
+                    CellRef tmp[4];
+                    for (int t = 0; t < 4; ++t) {
+                        const CellRef c = copy(sub[4 * ((w + t) % 4) + t], 0, base + t);
+                        tmp[t] = MIX[m][t] == 1 ? c : CellRef{0, 1, (uint16_t)(base + t)};
+                    }
+                    copy(tmp[0], 0, base + 4); copy(tmp[1], 1, base + 4);
+                    copy(tmp[2], 0, base + 5); copy(tmp[3], 1, base + 5);
+                    copy(CellRef{0, 2, (uint16_t)(base + 4)}, 0, base + 6);
+                    copy(CellRef{0, 2, (uint16_t)(base + 5)}, 1, base + 6);
+                    mixed[4 * w + m] = CellRef{0, 2, (uint16_t)(base + 6)};
+                }
+        } else {
+            for (int w = 0; w < 4; ++w)
+                for (int j = 0; j < 4; ++j) mixed[4 * w + j] = sub[4 * ((w + j) % 4) + j];  // :236-237
+        }
+        const int A = R <= 9 ? B + 128 : 1344;
+        for (int i = 0; i < 16; ++i) {  // :250-261
+            copy(mixed[i], 0, A + i);
+            copy(round_key_cell(R, i), 1, A + i);
+            s[i] = CellRef{0, 2, (uint16_t)(A + i)};
+        }
+    }
+    return n;
+}
+
+inline int key_copy_graph(CopyEdge *e) {
+    int n = 0;
+    auto copy = [&](CellRef src, uint8_t space, uint8_t col, int row) {
+        e[n++] = CopyEdge{space, col, (uint16_t)row, src.space, src.col, src.row};
+        return CellRef{space, col, (uint16_t)row};
+    };
+    for (int rho = 1; rho <= 10; ++rho) {  // assign_round, src/key_schedule.rs:122-224
+        const int B = 40 * (rho - 1), W = 16 + 8 * (rho - 1);
+        static const int rot[4] = {13, 14, 15, 12};
+        CellRef shifted[4], rconned[4], next[4];
+        for (int i = 0; i < 4; ++i) shifted[i] = copy(round_key_cell(rho - 1, rot[i]), 2, 0, W + i);   // :141-154
+        for (int i = 0; i < 4; ++i) copy(shifted[i], 1, 0, B + i);                                      // sbox rows
+        for (int i = 0; i < 4; ++i) {                                                                   // :189-194
+            copy(CellRef{1, 1, (uint16_t)(B + i)}, 1, 0, B + 4 + i);
+            copy(CellRef{2, 0, (uint16_t)(W + 4 + i)}, 1, 1, B + 4 + i);
+            rconned[i] = CellRef{1, 2, (uint16_t)(B + 4 + i)};
+        }
+        for (int i = 0; i < 4; ++i) {                                                                   // :197-204
+            copy(round_key_cell(rho - 1, i), 1, 0, B + 8 + i);
+            copy(rconned[i], 1, 1, B + 8 + i);
+            next[i] = CellRef{1, 2, (uint16_t)(B + 8 + i)};
+        }
+        for (int wd = 1; wd < 4; ++wd)                                                                  // :207-216
+            for (int i = 0; i < 4; ++i) {
+                copy(round_key_cell(rho - 1, 4 * wd + i), 1, 0, B + 8 + 4 * wd + i);
+                copy(next[i], 1, 1, B + 8 + 4 * wd + i);
+                next[i] = CellRef{1, 2, (uint16_t)(B + 8 + 4 * wd + i)};
+            }
+        for (int i = 0; i < 16; ++i) copy(CellRef{1, 2, (uint16_t)(B + 8 + i)}, 1, 0, B + 24 + i);      // :218-221
+    }
+    return n;
+}
+
 }  // namespace aesw

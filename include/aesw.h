@@ -135,6 +135,22 @@ int aesw_selector_tags(uint8_t enc_tag[AESW_AES_ROWS], uint8_t key_tag[AESW_KEY_
 int aesw_assemble_selectors(uint32_t k, uint32_t n_sets, uint64_t n_blocks, uint8_t *selectors,
                             uint8_t *fixed);
 
+/* Equality constraints for keygen, input independent: every copy_advice() of one encrypt() call
+ * (src/aes128.rs:154-301, AESW_BLOCK_COPIES edges) and of schedule_keys() (src/key_schedule.rs:80-224,
+ * AESW_KEY_COPIES edges), in the reference's call order.  A cell is (space, col, row): space 0 = the block's
+ * slab (columns x/y/z of its column set, block-relative row), 1 = the key slab (columns x/y/z of set 0,
+ * rows 0..399), 2 = words_column (rows 0..95); col is 0..2 (0 for words_column). */
+typedef struct aesw_copy_edge {
+    uint8_t dst_space, dst_col;
+    uint16_t dst_row;
+    uint8_t src_space, src_col;
+    uint16_t src_row;
+} aesw_copy_edge;
+#define AESW_BLOCK_COPIES 1952u
+#define AESW_KEY_COPIES 640u
+int aesw_block_copy_graph(aesw_copy_edge edges[AESW_BLOCK_COPIES]);
+int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]);
+
 /* ---- device-pointer entry points (asynchronous on `stream`) -------------- */
 /* stream is a hipStream_t passed as void* (NULL = the default stream).
  * All pointers are device pointers on aesw_device(ctx); column buffers must be

@@ -572,6 +572,14 @@ uint32_t aesw_o_circuit_num_selectors(const aesw_o_circuit *c) { return c->n_sel
 uint64_t aesw_o_circuit_num_rows(const aesw_o_circuit *c) { return c->n_rows; }
 uint64_t aesw_o_circuit_num_regions(const aesw_o_circuit *c) { return c->n_regions; }
 uint64_t aesw_o_circuit_num_copies(const aesw_o_circuit *c) { return c->n_copies; }
+int aesw_o_circuit_copies(const aesw_o_circuit *c, uint64_t *out) {
+    if (!c || !out || !c->record_copies) return AESW_O_ERR_ARG;
+    for (uint64_t i = 0; i < c->n_copies; ++i) {
+        out[4 * i + 0] = c->copies[i].a.col; out[4 * i + 1] = c->copies[i].a.row;
+        out[4 * i + 2] = c->copies[i].b.col; out[4 * i + 3] = c->copies[i].b.row;
+    }
+    return AESW_O_OK;
+}
 uint64_t aesw_o_circuit_column_height(const aesw_o_circuit *c, uint32_t col) {
     return col < c->n_advice ? c->h_adv[col] : 0;
 }

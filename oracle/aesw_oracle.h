@@ -124,6 +124,8 @@ uint32_t aesw_o_circuit_num_selectors(const aesw_o_circuit *c);
 uint64_t aesw_o_circuit_num_rows(const aesw_o_circuit *c);
 uint64_t aesw_o_circuit_num_regions(const aesw_o_circuit *c);
 uint64_t aesw_o_circuit_num_copies(const aesw_o_circuit *c);
+/* the recorded copy_advice() calls, in call order: out[4*i..] = source column, source row, copy column, copy row */
+int aesw_o_circuit_copies(const aesw_o_circuit *c, uint64_t *out);
 uint64_t aesw_o_circuit_column_height(const aesw_o_circuit *c, uint32_t advice_col);
 const uint8_t *aesw_o_circuit_advice(const aesw_o_circuit *c, uint32_t col);
 const uint8_t *aesw_o_circuit_advice_assigned(const aesw_o_circuit *c, uint32_t col);

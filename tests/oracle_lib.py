@@ -64,6 +64,7 @@ class Oracle:
             f = getattr(L, "aesw_o_circuit_" + name)
             f.argtypes = [V]
             f.restype = U64
+        L.aesw_o_circuit_copies.argtypes = [V, V]
         L.aesw_o_circuit_column_height.argtypes = [V, U32]
         L.aesw_o_circuit_column_height.restype = U64
         for name in ("advice", "advice_assigned", "selector"):
@@ -226,6 +227,12 @@ class Circuit:
     @property
     def num_copies(self):
         return self.L.aesw_o_circuit_num_copies(self.h)
+
+    def copies(self) -> np.ndarray:
+        """[num_copies, 4] = (source column, source row, copy column, copy row), in copy_advice() call order."""
+        out = np.zeros((self.num_copies, 4), np.uint64)
+        assert self.L.aesw_o_circuit_copies(self.h, _p(out)) == 0
+        return out
 
     def column_height(self, col):
         return self.L.aesw_o_circuit_column_height(self.h, col)

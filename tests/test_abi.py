@@ -84,6 +84,39 @@ def test_values_layout_geometry(pkg, oracle):
         pkg.layout_index(7, 1)
 
 
+def test_copy_graphs_equal_the_copies_of_synthesize(pkg, oracle):
+    """aesw_block_copy_graph / aesw_key_copy_graph, placed with aesw_block_placement, == every copy_advice() the restated
+    synthesize() records, in the same order (K=16, N=3: blocks in three column sets)."""
+    k, n_sets, n = 16, 3, 120
+    rng = np.random.default_rng(21)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    be, ke = pkg.block_copy_graph(), pkg.key_copy_graph()
+    assert len(be) == 1952 and len(ke) == 640
+    words_col = 3 * n_sets
+
+    def place(space, col, row, set_, row0):
+        col, row = col.astype(np.uint64), row.astype(np.uint64)
+        c = np.where(space == 0, 3 * set_ + col, np.where(space == 1, col, words_col))
+        r = np.where(space == 0, row0 + row, row)
+        return c.astype(np.uint64), r.astype(np.uint64)
+
+    expect = []
+    sc, sr = place(ke["src_space"], ke["src_col"], ke["src_row"], 0, 0)
+    dc, dr = place(ke["dst_space"], ke["dst_col"], ke["dst_row"], 0, 0)
+    expect.append(np.stack([sc, sr, dc, dr], axis=1))
+    for b in range(n):
+        s, r0 = pkg.block_placement(k, n_sets, b)
+        sc, sr = place(be["src_space"], be["src_col"], be["src_row"], s, r0)
+        dc, dr = place(be["dst_space"], be["dst_col"], be["dst_row"], s, r0)
+        expect.append(np.stack([sc, sr, dc, dr], axis=1))
+    expect = np.concatenate(expect)
+    with oracle.circuit(k, n_sets, key, pts) as c:
+        got = c.copies()
+    assert got.shape == expect.shape
+    assert np.array_equal(got, expect)
+
+
 def test_block_placement_mirrors_aes_callable(pkg, oracle):
     """aesw_block_placement == where the oracle's restated aes_callable() puts blocks."""
     assert pkg.block_capacity(20, 5) == 769 + 4 * 771 == 3853
