@@ -76,6 +76,12 @@ int main(void) {
     int32_t idx[AESW_AES_ROWS], kidx[AESW_KEY_ROWS];
     for (int l = 0; l < 3; ++l) for (int c = 0; c < 3; ++c) CHECK(aesw_layout_index(l, c, idx));
     for (int c = 0; c < 3; ++c) { CHECK(aesw_packed_index(c, idx)); CHECK(aesw_key_packed_index(c, kidx)); }
+    {
+        aesw_copy_edge *be = malloc(sizeof(aesw_copy_edge) * AESW_BLOCK_COPIES), *ke = malloc(sizeof(aesw_copy_edge) * AESW_KEY_COPIES);
+        CHECK(aesw_block_copy_graph(be));
+        CHECK(aesw_key_copy_graph(ke));
+        free(be); free(ke);
+    }
     uint8_t *sel = malloc((size_t)(5 * 2 + 1) << 14), *fixed = malloc((size_t)1 << 14);
     CHECK(aesw_assemble_selectors(14, 2, 15, sel, fixed));
     free(sel); free(fixed);
