@@ -82,6 +82,7 @@ SYMBOLS = {
 HOST_SYMBOLS = {
     "aesw_host_aes_circuit_run": (_I, [_P, _U32, _U32, _P, _P, _U64, _I, _I, _I, C.POINTER(_P)]),
     "aesw_host_circuit_copies": (_I, [_P, _P]),
+    "aesw_host_aes_circuit_columns": (_I, [_P, _U32, _U32, _P, _P, _U64, C.POINTER(_P)]),
     "aesw_host_key_circuit_run": (_I, [_P, _U32, _P, C.POINTER(_P)]),
     "aesw_host_circuit_free": (None, [_P]),
     "aesw_host_circuit_verify": (_I, [_P, C.c_char_p, C.c_size_t]),
@@ -562,6 +563,18 @@ class HostCircuit:
         rc = ctx._lib.aesw_host_aes_circuit_run(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0],
                                                 1 if with_witnesses else 0, 1 if skip_schedule_key else 0,
                                                 3 if streaming else (2 if values_only else (1 if bulk_assign else 0)), C.byref(h))
+        if rc:
+            raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
+        return cls(ctx._lib, h.value)
+
+    @classmethod
+    def aes_columns(cls, ctx: "Context", k: int, n_sets: int, key, pts) -> "HostCircuit":
+        """The same circuit without running a region: whole advice columns from the device witness, selectors, fixed
+        column, table and equality constraints from the library's keygen data (aesw_host_aes_circuit_columns)."""
+        key = np.ascontiguousarray(key, np.uint8).reshape(16)
+        pts = np.ascontiguousarray(pts, np.uint8).reshape(-1, 16)
+        h = C.c_void_p()
+        rc = ctx._lib.aesw_host_aes_circuit_columns(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0], C.byref(h))
         if rc:
             raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
         return cls(ctx._lib, h.value)

@@ -177,6 +177,93 @@ int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const 
     });
 }
 
+// The whole circuit without running a single region: what a host with bulk column access does.  Advice columns are the
+// device witness placed by aesw_block_placement, selectors / fixed column / equality constraints / table are the
+// library's input-independent keygen data.  MockProver::verify() then checks every lookup, the rcon gate and all copies.
+int aesw_host_aes_circuit_columns(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16], const uint8_t *pts, uint64_t n,
+                                  aesw_host_circuit **out) {
+    if (!ctx || !key || (n && !pts) || !out || k < 11 || k > 26 || n_sets == 0 || n_sets > 64) return AESW_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded([&] {
+        if (n > aesw_block_capacity(k, n_sets)) throw Panic(Panic::Capacity, "AES calls too many. doesn't fit in the rows");
+        std::unique_ptr<aesw_host_circuit> c(new aesw_host_circuit{});
+        MockProver &p = c->prover;
+        (void)FixedAes128Config::configure(p.cs, k, n_sets);  // columns, lookups, the rcon gate: as configure() registers them
+        Assembly &a = p.assembly;
+        a.k = k;
+        a.n_rows = (uint64_t)1 << k;
+        a.advice.assign(p.cs.n_advice, std::vector<uint8_t>(a.n_rows, 0));
+        a.advice_assigned.assign(p.cs.n_advice, std::vector<uint8_t>(a.n_rows, 0));
+        a.fixed.assign(p.cs.n_fixed, std::vector<uint8_t>(a.n_rows, 0));
+        a.fixed_assigned.assign(p.cs.n_fixed, std::vector<uint8_t>(a.n_rows, 0));
+        a.selectors.assign(p.cs.n_selectors, std::vector<uint8_t>(a.n_rows, 0));
+        a.table.assign(p.cs.n_table, std::vector<uint8_t>(AESW_TABLE_ROWS, 0));
+        auto chk = [](int rc, const char *what) { if (rc != AESW_OK) throw Error(Error::Synthesis, std::string(what) + ": " + aesw_strerror(rc)); };
+        // device witness, dense
+        std::vector<uint8_t> x(n * AESW_AES_ROWS), y(n * AESW_AES_ROWS), z(n * AESW_AES_ROWS);
+        std::vector<uint8_t> kw(AESW_WORDS_ROWS), kx(AESW_KEY_ROWS), ky(AESW_KEY_ROWS), kz(AESW_KEY_ROWS);
+        aesw_key_slab ks{kw.data(), kx.data(), ky.data(), kz.data()};
+        chk(aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks), "aesw_schedule_key");
+        if (n) chk(aesw_encrypt_witness(ctx, pts, nullptr, 0, n, AESW_LAYOUT_DENSE, x.data(), y.data(), z.data(), nullptr, nullptr), "aesw_encrypt_witness");
+        chk(aesw_lookup_table(ctx, a.table[0].data(), a.table[1].data(), a.table[2].data(), a.table[3].data()), "aesw_lookup_table");
+        // advice columns
+        const uint32_t words_col = 3 * n_sets;
+        uint8_t em[3][AESW_AES_ROWS], km[3][AESW_KEY_ROWS];  // which cells the reference assigns at all
+        for (int j = 0; j < 3; ++j) {
+            int32_t ei[AESW_AES_ROWS], ki[AESW_KEY_ROWS];
+            chk(aesw_packed_index(j, ei), "aesw_packed_index");
+            chk(aesw_key_packed_index(j, ki), "aesw_key_packed_index");
+            for (uint32_t r = 0; r < AESW_AES_ROWS; ++r) em[j][r] = ei[r] >= 0;
+            for (uint32_t r = 0; r < AESW_KEY_ROWS; ++r) km[j][r] = ki[r] >= 0;
+        }
+        const uint8_t *kcols[3] = {kx.data(), ky.data(), kz.data()};
+        for (int j = 0; j < 3; ++j)
+            for (uint32_t r = 0; r < AESW_KEY_ROWS; ++r)
+                if (km[j][r]) { a.advice[j][r] = kcols[j][r]; a.advice_assigned[j][r] = 1; }
+        for (uint32_t r = 0; r < AESW_WORDS_ROWS; ++r) { a.advice[words_col][r] = kw[r]; a.advice_assigned[words_col][r] = 1; }
+        std::vector<uint32_t> bset(n);
+        std::vector<uint64_t> brow(n);
+        const uint8_t *cols[3] = {x.data(), y.data(), z.data()};
+        for (uint64_t b = 0; b < n; ++b) {
+            chk(aesw_block_placement(k, n_sets, b, &bset[b], &brow[b]), "aesw_block_placement");
+            for (int j = 0; j < 3; ++j) {
+                uint8_t *dst = a.advice[3 * bset[b] + j].data() + brow[b], *asg = a.advice_assigned[3 * bset[b] + j].data() + brow[b];
+                const uint8_t *src = cols[j] + b * AESW_AES_ROWS;
+                for (uint32_t r = 0; r < AESW_AES_ROWS; ++r)
+                    if (em[j][r]) { dst[r] = src[r]; asg[r] = 1; }
+            }
+        }
+        // selectors + fixed column
+        std::vector<uint8_t> sel((size_t)(5 * n_sets + 1) * a.n_rows), fixed(a.n_rows);
+        chk(aesw_assemble_selectors(k, n_sets, n, sel.data(), fixed.data()), "aesw_assemble_selectors");
+        for (uint32_t s = 0; s < p.cs.n_selectors; ++s) std::memcpy(a.selectors[s].data(), sel.data() + (size_t)s * a.n_rows, a.n_rows);
+        a.fixed[0] = fixed;
+        a.fixed_assigned[0] = a.selectors[5 * n_sets];  // the round constant is assigned exactly where q_eq_rcon is enabled
+        // equality constraints
+        std::vector<aesw_copy_edge> be(AESW_BLOCK_COPIES), ke(AESW_KEY_COPIES);
+        chk(aesw_block_copy_graph(be.data()), "aesw_block_copy_graph");
+        chk(aesw_key_copy_graph(ke.data()), "aesw_key_copy_graph");
+        auto cell = [&](uint8_t space, uint8_t col, uint16_t row, uint32_t set, uint64_t row0) {
+            if (space == 0) return Cell{Column{Any::Advice, 3 * set + col}, row0 + row};
+            if (space == 1) return Cell{Column{Any::Advice, (uint32_t)col}, (uint64_t)row};
+            return Cell{Column{Any::Advice, words_col}, (uint64_t)row};
+        };
+        a.copies.reserve(ke.size() + n * be.size());
+        for (const aesw_copy_edge &e : ke) a.copies.emplace_back(cell(e.dst_space, e.dst_col, e.dst_row, 0, 0), cell(e.src_space, e.src_col, e.src_row, 0, 0));
+        for (uint64_t b = 0; b < n; ++b)
+            for (const aesw_copy_edge &e : be)
+                a.copies.emplace_back(cell(e.dst_space, e.dst_col, e.dst_row, bset[b], brow[b]), cell(e.src_space, e.src_col, e.src_row, bset[b], brow[b]));
+        // ciphertext cells (what encrypt() returns)
+        c->outputs.resize(n);
+        for (uint64_t b = 0; b < n; ++b)
+            for (uint32_t i = 0; i < 16; ++i) {
+                const uint64_t r = brow[b] + AESW_AES_ROWS - 16 + i;
+                c->outputs[b].push_back(AssignedCell{Cell{Column{Any::Advice, 3 * bset[b] + 2}, r}, Value::of(a.advice[3 * bset[b] + 2][r])});
+            }
+        *out = c.release();
+    });
+}
+
 int aesw_host_key_circuit_run(aesw_ctx *ctx, uint32_t k, const uint8_t key[16], aesw_host_circuit **out) {
     if (!ctx || !key || !out || k < 9 || k > 26) return AESW_ERR_INVALID_ARG;
     *out = nullptr;

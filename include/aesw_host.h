@@ -43,6 +43,12 @@ typedef struct aesw_host_circuit aesw_host_circuit;
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16],
                               const uint8_t *pts, uint64_t n, int with_witnesses,
                               int skip_schedule_key, int assign_mode, aesw_host_circuit **out);
+/* The same circuit WITHOUT running a region: advice columns = the device witness placed by aesw_block_placement, selectors /
+ * fixed column / table / equality constraints = the library's input-independent keygen data (aesw_assemble_selectors,
+ * aesw_lookup_table, aesw_block_copy_graph, aesw_key_copy_graph).  What a host with bulk column access does; verify() then
+ * checks every lookup, the rcon gate and all copy constraints on it.  num_regions is 0. */
+int aesw_host_aes_circuit_columns(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16],
+                                  const uint8_t *pts, uint64_t n, aesw_host_circuit **out);
 /* key_schedule.rs TestCircuit: 3 advice columns + words_column, schedule_keys only. */
 int aesw_host_key_circuit_run(aesw_ctx *ctx, uint32_t k, const uint8_t key[16],
                               aesw_host_circuit **out);

@@ -115,6 +115,44 @@ def test_streaming_assign_overlaps_device_and_host(ctx, pkg, oracle):
         ctx.set_option("chunk_blocks", 1 << 15)
 
 
+def test_whole_circuit_from_columns_and_keygen_data(ctx, pkg, oracle):
+    """No region is run: advice columns are the device witness placed by aesw_block_placement, selectors / fixed column /
+    table / equality constraints are the library's input-independent keygen data.  The result must be the very circuit the
+    restated synthesize() builds -- cells, assigned masks, selectors, fixed column, and the copies in the same order -- and
+    MockProver must accept it and reject a corrupted byte."""
+    rng = np.random.default_rng(0xA35128 + 12)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (130, 16), dtype=np.uint8)
+    pts[3] = key ^ 0xFF
+    with pkg.HostCircuit.aes_columns(ctx, 16, 3, key, pts) as mock, oracle.circuit(16, 3, key, pts) as o:
+        assert mock.verify() == (0, "")
+        assert mock.num_regions == 0 and mock.closure_calls == 0
+        assert mock.num_advice == o.num_advice and mock.num_selectors == o.num_selectors and mock.num_copies == o.num_copies
+        for c in range(mock.num_advice):
+            assert np.array_equal(mock.advice_assigned(c), o.advice_assigned(c)), c
+            assert np.array_equal(mock.advice(c), o.advice(c)), c
+        for s_ in range(mock.num_selectors):
+            assert np.array_equal(mock.selector(s_), o.selector(s_)), s_
+        assert np.array_equal(mock.fixed(), o.fixed())
+        oc = o.copies()           # (source col, source row, copy col, copy row)
+        mc = mock.copies()        # (copy col, copy row, original col, original row)
+        assert np.array_equal(mc[:, [2, 3, 0, 1]], oc)
+        t = oracle.lookup_table()
+        for c in range(4):
+            assert np.array_equal(mock.table(c), t[c])
+        for b in (0, 3, 45, 46, 129):
+            assert np.array_equal(mock.ciphertext(b), o.ciphertext(b))
+        mock.poke(1, 400 + 1360 * 5 + 40, int(mock.advice(1)[400 + 1360 * 5 + 40]) ^ 4)
+        assert mock.verify()[0] == 8
+    with pytest.raises(pkg.AeswError) as e:
+        pkg.HostCircuit.aes_columns(ctx, 16, 1, key, pts)   # 46 blocks fit one set at K = 16
+    assert e.value.status == 5
+    # the reference's own integration test, K = 20, N = 3, 1 000 blocks
+    with pkg.HostCircuit.aes_columns(ctx, 20, 3, np.zeros(16, np.uint8), np.zeros((1000, 16), np.uint8)) as mock:
+        assert mock.verify() == (0, "")
+        assert mock.ciphertext(0).tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
+
+
 def test_bulk_assign_equals_per_region(ctx, pkg, oracle):
     """one 1 360-row region per block (after the first) == the reference's 1 360 one-row regions:
     same advice cells, selectors, fixed column and the same SET of equality constraints; far fewer regions."""
