@@ -368,7 +368,12 @@ def main():
             hc = pkg.HostCircuit.aes(ctx, k, n_sets, hkey, hpt, streaming=True)
             dts = time.perf_counter() - t0
             hc.close()
+            t0 = time.perf_counter()
+            hc = pkg.HostCircuit.aes_columns(ctx, k, n_sets, hkey, hpt)
+            dtc = time.perf_counter() - t0
+            hc.close()
             extras["host_synthesize"] = {"circuit": "FixedAes128Config<20,3>, %d blocks (full)" % nn, "seconds": dt,
+                                         "whole_columns_blocks_per_s": nn / dtc,
                                          "streaming_values_only_blocks_per_s": nn / dts,
                                          "blocks_per_s": nn / dt, "regions_per_s": regions / dt,
                                          "bulk_assign_blocks_per_s": nn / dtb,

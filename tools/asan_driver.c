@@ -94,6 +94,14 @@ int main(void) {
         CHECK(aesw_host_circuit_verify(hc, msg, sizeof msg));
         aesw_host_circuit_free(hc);
     }
+    {   /* the whole circuit from columns and keygen data */
+        aesw_host_circuit *hc = NULL;
+        char msg[256];
+        CHECK(aesw_host_aes_circuit_columns(ctx, 14, 2, key, pt, 20, &hc));
+        CHECK(aesw_host_circuit_verify(hc, msg, sizeof msg));
+        aesw_host_circuit_free(hc);
+        if (aesw_host_aes_circuit_columns(ctx, 14, 2, key, pt, 40, &hc) != AESW_ERR_CAPACITY) { fprintf(stderr, "columns: capacity error expected\n"); return 1; }
+    }
     {   /* keygen pass, capacity panic, missing key */
         aesw_host_circuit *hc = NULL;
         CHECK(aesw_host_aes_circuit_run(ctx, 14, 2, key, pt, 20, 0, 0, 0, &hc));
