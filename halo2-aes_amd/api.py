@@ -17,11 +17,12 @@ import numpy as np
 from . import constants as K
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libaesw.so"
+LIB_PATH = _PKG / "libaesw.so"            # HIP kernels + the C ABI of include/aesw.h
+HOST_LIB_PATH = _PKG / "libaesw_host.so"  # C++ mirror of the reference's host interface (include/aesw_host.h), above the C ABI
 
 STATUS = {
     0: "AESW_OK", 1: "AESW_ERR_INVALID_ARG", 2: "AESW_ERR_NO_DEVICE", 3: "AESW_ERR_HIP", 4: "AESW_ERR_NOMEM",
-    5: "AESW_ERR_CAPACITY", 6: "AESW_ERR_NO_KEY", 7: "AESW_ERR_MISMATCH", 8: "AESW_ERR_UNSATISFIED",
+    5: "AESW_ERR_CAPACITY", 6: "AESW_ERR_NO_KEY", 7: "AESW_ERR_MISMATCH", 8: "AESW_ERR_UNSATISFIED", 9: "AESW_ERR_COMM",
 }
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_CAPACITY, ERR_NO_KEY, ERR_MISMATCH = range(8)
 
@@ -73,6 +74,13 @@ SYMBOLS = {
     "aesw_lookup_table": (_I, [_P, _P, _P, _P, _P]),
     "aesw_host_alloc": (_P, [C.c_size_t]),
     "aesw_host_free": (None, [_P]),
+    "aesw_comm_unique_id": (_I, [_P]),
+    "aesw_comm_create": (_I, [_P, _I, _I, _P, C.POINTER(_P)]),
+    "aesw_comm_destroy": (None, [_P]),
+    "aesw_comm_set_max_message": (_I, [_P, _U64]),
+    "aesw_comm_last_error": (C.c_char_p, []),
+    "aesw_gather_offsets": (_I, [_I, _P, _P, C.POINTER(_U64)]),
+    "aesw_gather_columns_device": (_I, [_P, _I, _I, _P, _P, _P, _P, _P]),
     "aesw_set_option": (_I, [_P, C.c_char_p, _I64]),
     "aesw_get_option": (_I, [_P, C.c_char_p, C.POINTER(_I64)]),
     "aesw_uses_xtime_path": (_I, [_P]),
@@ -103,6 +111,26 @@ HOST_SYMBOLS = {
 }
 
 _lib = None
+_host_lib = None
+
+
+def load_host_library(path: Path | None = None) -> C.CDLL:
+    """Load libaesw_host.so (in-tree): the host-side mirror.  It links against libaesw.so and holds no device code."""
+    global _host_lib
+    if _host_lib is not None and path is None:
+        return _host_lib
+    load_library()  # libaesw.so first: the mirror's NEEDED entry resolves to the copy already mapped
+    p = Path(path) if path else HOST_LIB_PATH
+    if not p.exists():
+        raise FileNotFoundError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+    lib = C.CDLL(str(p))
+    for name, (res, args) in HOST_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _host_lib = lib
+    return lib
 
 
 def load_library(path: Path | None = None) -> C.CDLL:
@@ -123,8 +151,8 @@ def load_library(path: Path | None = None) -> C.CDLL:
         raise FileNotFoundError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no fallback implementation." % p)
-    lib = C.CDLL(str(p))
-    for name, (res, args) in list(SYMBOLS.items()) + list(HOST_SYMBOLS.items()):
+    lib = C.CDLL(str(p))  # RTLD_LOCAL: two builds of the library can sit in one process (tools/ab_lib.py)
+    for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = res
         fn.argtypes = args
@@ -551,21 +579,27 @@ class HostCircuit:
     def __init__(self, lib, handle):
         self._lib, self._h = lib, C.c_void_p(handle)
 
+    @staticmethod
+    def _host():
+        return load_host_library()
+
     @classmethod
     def aes(cls, ctx: "Context", k: int, n_sets: int, key, pts, with_witnesses: bool = True,
             skip_schedule_key: bool = False, bulk_assign: bool = False, values_only: bool = False,
-            streaming: bool = False) -> "HostCircuit":
+            streaming: bool = False, dense: bool = False) -> "HostCircuit":
         """load_enc_full_table, schedule_key(key), encrypt(pts[b]) for every block: TestAesCircuit /
-        Aes128BenchCircuit (src/aes128.rs:376-407, benches/aes128.rs:30-61)."""
+        Aes128BenchCircuit (src/aes128.rs:376-407, benches/aes128.rs:30-61).  The device witness travels in the
+        PACKED layout (assigned cells only) unless values_only / streaming (VALUES) or dense is asked for."""
         key = np.ascontiguousarray(key, np.uint8).reshape(16)
         pts = np.ascontiguousarray(pts, np.uint8).reshape(-1, 16)
         h = C.c_void_p()
-        rc = ctx._lib.aesw_host_aes_circuit_run(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0],
-                                                1 if with_witnesses else 0, 1 if skip_schedule_key else 0,
-                                                3 if streaming else (2 if values_only else (1 if bulk_assign else 0)), C.byref(h))
+        lib = cls._host()
+        mode = 3 if streaming else (2 if values_only else (1 if bulk_assign else (4 if dense else 0)))
+        rc = lib.aesw_host_aes_circuit_run(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0],
+                                           1 if with_witnesses else 0, 1 if skip_schedule_key else 0, mode, C.byref(h))
         if rc:
-            raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
-        return cls(ctx._lib, h.value)
+            raise AeswError(rc, lib.aesw_host_last_error().decode())
+        return cls(lib, h.value)
 
     @classmethod
     def aes_columns(cls, ctx: "Context", k: int, n_sets: int, key, pts) -> "HostCircuit":
@@ -574,20 +608,22 @@ class HostCircuit:
         key = np.ascontiguousarray(key, np.uint8).reshape(16)
         pts = np.ascontiguousarray(pts, np.uint8).reshape(-1, 16)
         h = C.c_void_p()
-        rc = ctx._lib.aesw_host_aes_circuit_columns(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0], C.byref(h))
+        lib = cls._host()
+        rc = lib.aesw_host_aes_circuit_columns(ctx._h, k, n_sets, _np_ptr(key), _np_ptr(pts), pts.shape[0], C.byref(h))
         if rc:
-            raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
-        return cls(ctx._lib, h.value)
+            raise AeswError(rc, lib.aesw_host_last_error().decode())
+        return cls(lib, h.value)
 
     @classmethod
     def key_schedule(cls, ctx: "Context", k: int, key) -> "HostCircuit":
         """key_schedule.rs TestCircuit (src/key_schedule.rs:245-320)."""
         key = np.ascontiguousarray(key, np.uint8).reshape(16)
         h = C.c_void_p()
-        rc = ctx._lib.aesw_host_key_circuit_run(ctx._h, k, _np_ptr(key), C.byref(h))
+        lib = cls._host()
+        rc = lib.aesw_host_key_circuit_run(ctx._h, k, _np_ptr(key), C.byref(h))
         if rc:
-            raise AeswError(rc, ctx._lib.aesw_host_last_error().decode())
-        return cls(ctx._lib, h.value)
+            raise AeswError(rc, lib.aesw_host_last_error().decode())
+        return cls(lib, h.value)
 
     def close(self):
         if self._h:

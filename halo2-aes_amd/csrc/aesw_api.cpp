@@ -22,7 +22,10 @@ struct aesw_ctx {
     uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
     uint8_t *d_rk = nullptr;      // 176 B: round keys of the key given to aesw_schedule_key*
     int16_t *d_pidx = nullptr;    // dense row -> packed index tables: enc[3][1360], key[3][400]
+    uint32_t *d_ftab[3] = {nullptr, nullptr, nullptr};  // flush descriptors per layout (aesw_layout.h "scheduled flush")
     bool have_key = false;
+    void *key_stream = nullptr;      // the stream the scheduled key's round keys were written on
+    hipEvent_t key_ready = nullptr;  // recorded behind the key launch of aesw_schedule_key_device: other streams wait on it
     bool xt = false;
     int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
@@ -30,7 +33,7 @@ struct aesw_ctx {
     int key_nt = 1;  // store flavour of key_kernel (one contiguous flush per column at the end): nontemporal 4-9 % ahead of sc1 (tools/keysweep.py)
     int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
-    bool xcd_remap = false;
+    bool xcd_remap = true;  // workgroups that share an XCD take one contiguous eighth of the block groups: +3-4 % at 2^20 blocks (tools/sweep.py xcd)
     int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
 #ifdef AESW_TRACE
     uint64_t *trace = nullptr;
@@ -137,6 +140,7 @@ const char *aesw_strerror(int status) {
     case AESW_ERR_NO_KEY: return "Keys should be scheduled";
     case AESW_ERR_MISMATCH: return "host value disagrees with the device witness";
     case AESW_ERR_UNSATISFIED: return "constraint system not satisfied";
+    case AESW_ERR_COMM: return "RCCL unavailable or a collective call failed";
     default: return "unknown status";
     }
 }
@@ -191,6 +195,13 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
         for (int r = 0; r < KEY_ROWS; ++r) pidx[3 * AES_ROWS + c * KEY_ROWS + r] = (int16_t)kk[r];
     }
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_pidx), pidx.size() * sizeof(int16_t)), "hipMalloc(pidx)");
+    for (int l = 0; l < 3 && rc == AESW_OK; ++l) {
+        std::vector<uint32_t> ft((size_t)flush_table_words(l));
+        build_flush_tables(l, ft.data());
+        T(hipMalloc(reinterpret_cast<void **>(&ctx->d_ftab[l]), ft.size() * sizeof(uint32_t)), "hipMalloc(flush table)");
+        if (rc == AESW_OK) T(hipMemcpy(ctx->d_ftab[l], ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(flush table)");
+    }
+    T(hipEventCreateWithFlags(&ctx->key_ready, hipEventDisableTiming), "hipEventCreate(key_ready)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_pidx, pidx.data(), pidx.size() * sizeof(int16_t), hipMemcpyHostToDevice), "hipMemcpy(pidx)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_fr_lut, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy(fr_lut)");
@@ -215,6 +226,9 @@ void aesw_destroy(aesw_ctx *ctx) {
         if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
         if (ctx->d_rk) (void)hipFree(ctx->d_rk);
         if (ctx->d_pidx) (void)hipFree(ctx->d_pidx);
+        for (uint32_t *t : ctx->d_ftab)
+            if (t) (void)hipFree(t);
+        if (ctx->key_ready) (void)hipEventDestroy(ctx->key_ready);
     }
     delete ctx;
 }
@@ -362,8 +376,12 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "waves_pbk")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->waves_pbk = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "nt_stores")) { ctx->nt = value != 0 ? 1 : 0; return AESW_OK; }
     if (!std::strcmp(name, "store_mode")) {
-        // 3 = diagnostic build of the flush (no stores, output is garbage): tools/ only, behind an env switch
-        const int max_mode = std::getenv("AESW_DIAGNOSTIC") ? 3 : 2;
+        // 3 = "leave the flush out" (output is garbage): exists only in -DAESW_DIAGNOSTIC builds of the library (tools/)
+#ifdef AESW_DIAGNOSTIC
+        const int max_mode = 5;
+#else
+        const int max_mode = 2;
+#endif
         if (value < 0 || value > max_mode) return AESW_ERR_INVALID_ARG;
         ctx->nt = (int)value;
         return AESW_OK;
@@ -400,9 +418,12 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
 static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
     // per-block keys: 3-wave groups (2 per CU) measured 3-4 % ahead of 2- and 1-wave groups at 2^20 blocks on two
     // boxes (tools/sweep.py 20 c2 packed waves); dense: 1..3 equal, 4 slower
-    if (pbk) return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_DENSE ? 1 : 3);
-    if (ctx->waves_shared) return ctx->waves_shared;
-    return 4;  // 64 blocks per group: line-aligned in every column, fewest table loads
+    // upper bound: a group's staging must stay below 64 KiB (16-bit LDS addresses in the flush descriptors)
+    const int max_waves = layout == AESW_LAYOUT_DENSE ? 2 : layout == AESW_LAYOUT_VALUES ? 4 : 3;
+    int w;
+    if (pbk) w = ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_DENSE ? 1 : 3);
+    else w = ctx->waves_shared ? ctx->waves_shared : (layout == AESW_LAYOUT_DENSE ? 2 : 3);
+    return w > max_waves ? max_waves : w;
 }
 
 // key_kernel alone (tools/keysweep.py, 2^20 keys): packed 4-wave groups, dense 2-wave groups
@@ -423,6 +444,9 @@ int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, co
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     KeyParams kp{d_key, ctx->d_tables, ko, ctx->d_rk, 1};
     HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, reinterpret_cast<hipStream_t>(stream)));
+    // a later encrypt on ANOTHER stream (the host-pointer entry points use the context's own) waits for these round keys
+    HIP_TRY(ctx, hipEventRecord(ctx->key_ready, reinterpret_cast<hipStream_t>(stream)));
+    ctx->key_stream = stream;
     ctx->have_key = true;
     return AESW_OK;
 }
@@ -459,7 +483,14 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
         HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, s));
     }
     const int km = per_block_keys ? 0 : (d_keys ? 1 : 2);
-    EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, d_x, d_y, d_z, d_ct,
+    if (km == 2 && stream != ctx->key_stream) {
+        // the round keys were written on another stream: order this launch behind them.  While a stream is being
+        // captured the wait would pull the key stream into the capture; capture on the stream the key was scheduled on.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->key_ready, 0));
+    }
+    EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, ctx->d_ftab[layout], d_x, d_y, d_z, d_ct,
                 per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n, 0, 0};
 #ifdef AESW_TRACE
     p.trace = ctx->trace;
@@ -618,9 +649,9 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         size_t o_x[2], o_y[2], o_z[2], o_w[2], o_kx[2], o_ky[2], o_kz[2];
         for (int i = 0; i < 2; ++i) {
             o_x[i] = take(chunk * sx); o_y[i] = take(chunk * sy); o_z[i] = take(chunk * sz);
-            const bool k = pbk && kemit;
-            o_w[i] = take(k ? chunk * WORDS_ROWS : 0); o_kx[i] = take(k ? chunk * kxs : 0);
-            o_ky[i] = take(k ? chunk * kys : 0); o_kz[i] = take(k ? chunk * kzs : 0);
+            const size_t kn = kemit ? (pbk ? chunk : 1) : 0;  // per-block keys: a key slab per block; shared key: one
+            o_w[i] = take(kn * WORDS_ROWS); o_kx[i] = take(kn * kxs);
+            o_ky[i] = take(kn * kys); o_kz[i] = take(kn * kzs);
         }
         rc = ensure_scratch(ctx, off ? off : 256);
         if (rc != AESW_OK) return rc;
@@ -650,23 +681,7 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         rc = ensure_bounce(ctx, bounce_need);
         if (rc != AESW_OK) return rc;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(d_pt.p, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
-    if (keys) HIP_TRY(ctx, hipMemcpyAsync(d_keys.p, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
-
-    if (!pbk && kemit) {
-        // shared key: one key slab, straight through
-        DevBuf w1, kx1, ky1, kz1;
-        HIP_TRY(ctx, w1.alloc(WORDS_ROWS)); HIP_TRY(ctx, kx1.alloc(kxs)); HIP_TRY(ctx, ky1.alloc(kys)); HIP_TRY(ctx, kz1.alloc(kzs));
-        rc = aesw_key_schedule_witness_device(ctx, d_keys.p, 1, layout, w1.p, kx1.p, ky1.p, kz1.p, nullptr, ctx->s_compute);
-        if (rc != AESW_OK) return rc;
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->s_compute));
-        if (ks->w) HIP_TRY(ctx, hipMemcpy(ks->w, w1.p, WORDS_ROWS, hipMemcpyDeviceToHost));
-        if (ks->kx) HIP_TRY(ctx, hipMemcpy(ks->kx, kx1.p, kxs, hipMemcpyDeviceToHost));
-        if (ks->ky) HIP_TRY(ctx, hipMemcpy(ks->ky, ky1.p, kys, hipMemcpyDeviceToHost));
-        if (ks->kz) HIP_TRY(ctx, hipMemcpy(ks->kz, kz1.p, kzs, hipMemcpyDeviceToHost));
-    }
-
-    // Whatever happens below, no copy may still be writing the caller's buffers when we return.
+    // Whatever happens below, no copy may still be reading or writing the caller's buffers when we return.
     struct SyncGuard {
         aesw_ctx *c;
         ~SyncGuard() {
@@ -683,6 +698,19 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
         HIP_TRY(ctx, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
     }
+    HIP_TRY(ctx, hipMemcpyAsync(d_pt.p, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
+    if (keys) HIP_TRY(ctx, hipMemcpyAsync(d_keys.p, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
+
+    if (!pbk && kemit) {
+        // shared key: one key slab, staged in stage 0's (still unused) key buffers of the scratch, copied back on s_compute
+        rc = aesw_key_schedule_witness_device(ctx, d_keys.p, 1, layout, dw[0].p, dkx[0].p, dky[0].p, dkz[0].p, nullptr, ctx->s_compute);
+        if (rc != AESW_OK) return rc;
+        if (ks->w) HIP_TRY(ctx, hipMemcpyAsync(ks->w, dw[0].p, WORDS_ROWS, hipMemcpyDeviceToHost, ctx->s_compute));
+        if (ks->kx) HIP_TRY(ctx, hipMemcpyAsync(ks->kx, dkx[0].p, kxs, hipMemcpyDeviceToHost, ctx->s_compute));
+        if (ks->ky) HIP_TRY(ctx, hipMemcpyAsync(ks->ky, dky[0].p, kys, hipMemcpyDeviceToHost, ctx->s_compute));
+        if (ks->kz) HIP_TRY(ctx, hipMemcpyAsync(ks->kz, dkz[0].p, kzs, hipMemcpyDeviceToHost, ctx->s_compute));
+    }
+
     // Drain stage s: wait for its D2H, then move bounce data into pageable destinations.
     uint64_t stage_b0[2] = {0, 0}, stage_m[2] = {0, 0};
     bool stage_busy[2] = {false, false};

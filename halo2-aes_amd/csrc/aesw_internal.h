@@ -15,6 +15,7 @@ struct EncParams {
     const uint8_t *keys;    // 16 or n*16; null when rk is used
     const uint32_t *rk;     // 44 words of a key scheduled earlier (aesw_schedule_key_device), or null
     const uint8_t *tables;  // 768: sbox | mul2 | mul3
+    const uint32_t *ftab;   // flush descriptors of the layout (build_flush_tables), flush_table_words(layout) words
     uint8_t *x, *y, *z;     // column buffers (16-byte aligned)
     uint8_t *ct;            // n*16 or null
     KeyOut key;             // per-block-key mode only
@@ -37,6 +38,9 @@ struct KeyParams {
 // key mode: 0 = per-block keys, 1 = shared key expanded in the kernel, 2 = shared key scheduled earlier (p.rk)
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, int store_mode,
                           uint32_t max_groups_in_flight, bool xcd_remap, uint32_t lds_pad, hipStream_t s);
+// flush-descriptor table of a layout (aesw_layout.h "scheduled flush"): size in 32-bit words, and the host-side builder
+int flush_table_words(int layout);
+void build_flush_tables(int layout, uint32_t *out);
 hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
 struct AssembleParams {

@@ -28,6 +28,7 @@
 namespace aesw {
 
 template <int V> struct IntC { static constexpr int value = V; };
+template <bool V> struct BoolC { static constexpr bool value = V; };
 
 constexpr int LANES = 64;
 constexpr int BPW = 16;  // blocks per wave
@@ -106,92 +107,106 @@ template <> struct PieceT<4> { using type = uint32_t; };
 // the kernel boundary (that costs dirty bytes / ~6 TB/s after the last wave has
 // finished); sc1 stores leave L2 as they are issued, so a launch ends with
 // nothing left to flush (MI355X_MICROARCH.md, "stores of each flavour").
+// Modes 3..5 (tools/ only) exist in -DAESW_DIAGNOSTIC builds alone: 3 = leave the flush out (compute + staging only),
+// 4 = flush only (no AES work, no staging writes: the store schedule fed from whatever LDS holds), 5 = as 4 without the
+// LDS reads.  Their output is garbage; they price the parts of a launch.
+#ifdef AESW_DIAGNOSTIC
+constexpr int NT_MODES = 6;
+#else
+constexpr int NT_MODES = 3;
+#endif
 template <int MODE>
 __device__ __forceinline__ void gstore(u32x4 *p, const u32x4 &v) {
-    if (MODE >= 3) return;
+    if (MODE == 3) return;
     // hipcc neither counts nor pads an asm store: the trailing s_nop 1 covers the ">64-bit store data
     // overwritten by the next instruction" hazard (cdna guide 5.7 item 1); nothing ever waits on these stores.
-    if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    if (MODE == 2 || MODE >= 4) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
     else if (MODE == 1) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
 template <int MODE>
 __device__ __forceinline__ void gstore(u32x2 *p, const u32x2 &v) {
-    if (MODE >= 3) return;
-    if (MODE == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+    if (MODE == 3) return;
+    if (MODE == 2 || MODE >= 4) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
     else if (MODE == 1) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+// wave-uniform base (SGPR pair) + 32-bit byte offset per lane: no 64-bit address arithmetic per piece
+template <int MODE>
+__device__ __forceinline__ void gstore_at(uint8_t *base, uint32_t off, const u32x4 &v) {
+    if (MODE == 3) return;
+    if (MODE == 2 || MODE >= 4) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base) : "memory");
+    else if (MODE == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(base + off));
+    else *reinterpret_cast<u32x4 *>(base + off) = v;
+}
+__device__ __forceinline__ uint8_t *uniform_ptr(uint8_t *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<uint8_t *>(((uint64_t)hi << 32) | lo);
+}
 
-// Whole-line flush after round R (aesw_layout.h flush_piece).  Lane = (block
-// lane>>3 (+8 in the second pass), 16-byte piece lane&7): 8 whole lines per
-// store instruction.  R must be a compile-time constant at the call site (the
-// round loop is fully unrolled) so every window offset folds to an immediate.
-//
-// Two phases per round, over all three columns: first every ds_read_b128 is
-// issued (unconditionally -- a piece that is not stored reads a harmless
-// in-range address), then the predicated stores.  With read -> wait -> store per
-// piece, a wave pays one LDS round trip per piece (8..18 per round, ~1 k cycles);
-// issued together the reads overlap and a wave's 10-round latency drops by ~40 %,
-// which is what bounds a launch with only two generations of waves (2^16 blocks).
-template <class W>
-struct FlushBatch {
-    static constexpr int MAXP = 2 * 3;  // pieces per column and round: 2 passes x at most 3 lines per block
-    u32x4 v[MAXP];
-    int P[MAXP];
-    bool ok[MAXP];
-    template <int R>
-    __device__ __forceinline__ void load(const uint8_t *lds, uint32_t stage, FlushState<W> &st, int lane) {
-        const int sub = lane & 7;
+// Scheduled whole-line flush (aesw_layout.h "scheduled flush").  A lane holds one descriptor word per store
+// instruction of its column (loaded once per workgroup from the host-built table, stage base added):
+//   bits 0..15  LDS address of the lane's 16-byte piece      bits 16..30  byte offset in the wave's global range
+// Round R issues all its ds_read_b128 first (their LDS round trips overlap), then the stores: 8 whole lines per
+// instruction.  FULL (16 valid blocks, the common case): only the last instruction of a round can have unused
+// slots, known at compile time; otherwise every piece is predicated with "offset < nvalid * stride".
+template <class W, bool ON>
+struct ColSched {
+    static constexpr int N = ON ? sched_first<W>(10) : 0;
+    uint32_t d[N > 0 ? N : 1];
+    __device__ __forceinline__ void load(const uint32_t *tab, int lane, uint32_t stage) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int lo = st.advance(R, h);
+        for (int i = 0; i < N; ++i) d[i] = tab[i * LANES + lane] + stage;
+    }
+};
+
+template <class W, int R>
+struct RoundBatch {
+    static constexpr int NI = sched_ninstr<W>(R), FIRST = sched_first<W>(R), NLINES = sched_nlines<W>(R);
+    u32x4 v[NI > 0 ? NI : 1];
+    template <int NT, class CS>
+    __device__ __forceinline__ void load(const uint8_t *lds, const CS &cs) {
 #pragma unroll
-            for (int t = 0; t < flush_maxc<W>(R); ++t) {
-                const int i = h * 3 + t;
-                const FlushPiece fp = st.piece(R, h, lo, sub, t);
-                ok[i] = fp.ok;
-                P[i] = fp.P;
-                // read unconditionally (a piece that is not stored reads some in-range LDS bytes): no branch
-                // between the reads, so they all overlap
-                v[i] = *reinterpret_cast<const u32x4 *>(lds + stage + fp.lds_off);
-            }
+        for (int i = 0; i < NI; ++i) {
+            if (NT == 5) v[i] = u32x4{cs.d[FIRST + i], 1u, 2u, 3u};
+            else v[i] = *reinterpret_cast<const u32x4 *>(lds + (cs.d[FIRST + i] & 0xffffu));
         }
     }
-    template <int R, int NT>
-    __device__ __forceinline__ void store(uint8_t *g) const {
+    template <int NT, bool FULL, class CS>
+    __device__ __forceinline__ void store(uint8_t *g, const CS &cs, uint32_t limit, int lane) const {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int t = 0; t < flush_maxc<W>(R); ++t) {
-                const int i = h * 3 + t;
-                if (ok[i]) gstore<NT>(reinterpret_cast<u32x4 *>(g + P[i]), v[i]);
-            }
+        for (int i = 0; i < NI; ++i) {
+            const uint32_t off = cs.d[FIRST + i] >> 16;
+            constexpr int last_slots = NLINES - 8 * (NI - 1);  // line slots in use in the round's last instruction
+            const bool ok = !FULL ? off < limit : (i == NI - 1 && last_slots < 8) ? lane < 8 * last_slots : true;
+            if (ok) gstore_at<NT>(g, off, v[i]);
         }
     }
 };
 
 template <int L>
-struct FlushStates {
-    FlushState<WinX<L>> x;
-    FlushState<WinY<L>> y;
-    FlushState<WinZ<L>> z;
-    __device__ __forceinline__ void init(int lane, int nvalid) { x.init(lane, nvalid); y.init(lane, nvalid); z.init(lane, nvalid); }
+struct Scheds {
+    ColSched<WinX<L>, Geo<L>::HAS_X> x;
+    ColSched<WinY<L>, true> y;
+    ColSched<WinZ<L>, true> z;
+    static constexpr int OFF_Y = ColSched<WinX<L>, Geo<L>::HAS_X>::N, OFF_Z = OFF_Y + ColSched<WinY<L>, true>::N,
+                         TOTAL = OFF_Z + ColSched<WinZ<L>, true>::N;
 };
 
-template <int L, int NT, int R>
-__device__ __forceinline__ void flush_round(const uint8_t *lds, uint32_t sx, uint32_t sy, uint32_t sz, uint8_t *gx, uint8_t *gy,
-                                            uint8_t *gz, FlushStates<L> &fs, int lane) {
-    if (NT >= 3) return;  // diagnostic builds only (store_mode 3): price the flush by leaving it out
-    FlushBatch<WinX<L>> bx;
-    FlushBatch<WinY<L>> by;
-    FlushBatch<WinZ<L>> bz;
-    if (Geo<L>::HAS_X) bx.template load<R>(lds, sx, fs.x, lane);
-    by.template load<R>(lds, sy, fs.y, lane);
-    bz.template load<R>(lds, sz, fs.z, lane);
-    if (Geo<L>::HAS_X) bx.template store<R, NT>(gx);
-    by.template store<R, NT>(gy);
-    bz.template store<R, NT>(gz);
+template <int L, int NT, int R, bool FULL>
+__device__ __forceinline__ void flush_round(const uint8_t *lds, uint8_t *gx, uint8_t *gy, uint8_t *gz, const Scheds<L> &sc,
+                                            int nvalid, int lane) {
+    if (NT == 3) return;  // -DAESW_DIAGNOSTIC builds only (store_mode 3): price the flush by leaving it out
+    RoundBatch<WinX<L>, R> bx;
+    RoundBatch<WinY<L>, R> by;
+    RoundBatch<WinZ<L>, R> bz;
+    if (Geo<L>::HAS_X) bx.template load<NT>(lds, sc.x);
+    by.template load<NT>(lds, sc.y);
+    bz.template load<NT>(lds, sc.z);
+    if (Geo<L>::HAS_X) bx.template store<NT, FULL>(gx, sc.x, (uint32_t)nvalid * Geo<L>::XS, lane);
+    by.template store<NT, FULL>(gy, sc.y, (uint32_t)nvalid * Geo<L>::YS, lane);
+    bz.template store<NT, FULL>(gz, sc.z, (uint32_t)nvalid * Geo<L>::ZS, lane);
 }
 
 // Fully contiguous: nvalid*STRIDE bytes from LDS stage to g.
@@ -234,9 +249,26 @@ template <int L> __host__ __device__ constexpr int enc_wave_lds(bool kemit) {
     return (kemit && Stage<L>::KEY_BYTES > Stage<L>::ENC_BYTES) ? Stage<L>::KEY_BYTES : Stage<L>::ENC_BYTES;
 }
 
-// Residency guard: two 4-wave groups of the packed shared-key kernel must fit one CU's 160 KiB
-// (hipOccupancyMaxActiveBlocksPerMultiprocessor: 81 920 B -> 2 groups, 82 000 B -> 1).
-static_assert(TAB_BYTES + RKS_BYTES + 4 * enc_wave_lds<PACKED>(false) <= 81920, "packed windows grew: 8 waves/CU no longer fit");
+// Residency / addressing guards: a packed group of 3 waves must stay below 64 KiB (16-bit LDS addresses in the
+// flush descriptors) and two of them must fit one CU's 160 KiB; dense: 2 waves.
+static_assert(TAB_BYTES + RKS_BYTES + 3 * enc_wave_lds<PACKED>(true) <= 65536, "packed windows grew: 3-wave groups no longer addressable");
+static_assert(TAB_BYTES + RKS_BYTES + 2 * enc_wave_lds<DENSE>(true) <= 65536, "dense windows grew: 2-wave groups no longer addressable");
+
+// words per layout of the flush-descriptor table the host uploads (x, then y, then z instructions, 64 lanes each)
+int flush_table_words(int layout) {
+    return (layout == DENSE ? Scheds<DENSE>::TOTAL : layout == VALUES ? Scheds<VALUES>::TOTAL : Scheds<PACKED>::TOTAL) * LANES;
+}
+template <int L>
+static void build_tables_for(uint32_t *out) {
+    if (Geo<L>::HAS_X) build_flush_table<WinX<L>>(out);
+    build_flush_table<WinY<L>>(out + Scheds<L>::OFF_Y * LANES);
+    build_flush_table<WinZ<L>>(out + Scheds<L>::OFF_Z * LANES);
+}
+void build_flush_tables(int layout, uint32_t *out) {
+    if (layout == DENSE) build_tables_for<DENSE>(out);
+    else if (layout == VALUES) build_tables_for<VALUES>(out);
+    else build_tables_for<PACKED>(out);
+}
 
 // One key-schedule round for every quad of the wave.
 template <int L, class KS, class T>
@@ -319,12 +351,19 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
 
     const int tid = threadIdx.x;
     const int lane0 = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it stays scalar
     const int waves = blockDim.x >> 6;
     const int w = lane0 & 3;
 
     const uint32_t shared_rk = TAB_BYTES;                           // 176 B, KM_SHARED only
-    const uint32_t stage0 = TAB_BYTES + RKS_BYTES + wave * WAVE_LDS;  // this wave's slab
+    const uint32_t stage0 = TAB_BYTES + RKS_BYTES + wave * WAVE_LDS;  // this wave's slab (below 64 KiB: launch_enc checks)
+    // flush descriptors: one dword per lane and store instruction, kept in registers for every group this workgroup handles
+    Scheds<L> sc;
+    if (NT != 3) {
+        if (G::HAS_X) sc.x.load(a.ftab, lane0, stage0 + St::OX);
+        sc.y.load(a.ftab + Scheds<L>::OFF_Y * LANES, lane0, stage0 + St::OY);
+        sc.z.load(a.ftab + Scheds<L>::OFF_Z * LANES, lane0, stage0 + St::OZ);
+    }
 
     // the first group's inputs first, so their latency hides behind the table load
     // Optional XCD-aware order (workgroups are dealt round-robin over the 8 XCDs): ids that share an
@@ -394,7 +433,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
 
         if (PBK) {
             const uint32_t kw = kw_next;
-            key_phase<L, KEMIT, false>(lds, stage, 0, kw, blk, w, tab, rkr);
+            if (NT < 4) key_phase<L, KEMIT, false>(lds, stage, 0, kw, blk, w, tab, rkr);
             if (KEMIT) {
                 wave_lds_fence();
                 key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
@@ -413,9 +452,9 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
         s.mb[1] = stage + St::OY + blk * St::SY + G::Y_MIXW * w;
         s.mb[2] = stage + St::OZ + blk * St::SZ + G::Z_MIXW * w;
 
-        uint8_t *gx = a.x + blk0 * G::XS;
-        uint8_t *gy = a.y + blk0 * G::YS;
-        uint8_t *gz = a.z + blk0 * G::ZS;
+        uint8_t *gx = uniform_ptr(a.x + blk0 * G::XS);
+        uint8_t *gy = uniform_ptr(a.y + blk0 * G::YS);
+        uint8_t *gz = uniform_ptr(a.z + blk0 * G::ZS);
 
         auto round = [&](int relx, int rely, int relz, uint32_t st, uint32_t rkw) -> uint32_t {
             const uint32_t sub = emit_sbox<L>(s, relx, rely, relz, st, tab);
@@ -428,34 +467,38 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
         using WX = typename St::WX;
         using WY = typename St::WY;
         using WZ = typename St::WZ;
-        FlushStates<L> fs;
-        fs.init(lane, nvalid);
-        uint32_t st = emit_head<L>(s, ptw, rkw(0));
-        // rounds 1..9 (+10), unrolled through a template parameter so that every window offset and
-        // flush bound is an immediate (a pragma-unrolled loop this large falls back to a runtime R)
-        auto step = [&](auto rc) {
-            constexpr int R = decltype(rc)::value;
-            st = round(WX::woff(R), WY::woff(R), WZ::woff(R), st, rkw(R));
-            if (R == 9) {
-                const uint32_t sub = emit_sbox<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), st, tab);
-                const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
-                st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkw(10));
-            }
-            wave_lds_fence();
-            if (R == 1) {
-                AESW_TRACE_POINT(2);
-                // a striding workgroup's next inputs travel while this group is flushed
-                ptw_next = load_word(a.pt, grp + gridDim.x);
-                if (PBK) kw_next = load_word(a.keys, grp + gridDim.x);
-            }
-            flush_round<L, NT, R>(lds, stage + St::OX, stage + St::OY, stage + St::OZ, gx, gy, gz, fs, lane);
-            wave_lds_fence();
-            if (R == 1) AESW_TRACE_POINT(3);
-            if (R == 5) AESW_TRACE_POINT(4);
-            if (R == 9) AESW_TRACE_POINT(5);
+        // Two copies of the round chain: a full wave (16 valid blocks) stores without per-piece predicates.
+        auto chain = [&](auto full_tag) -> uint32_t {
+            constexpr bool FULL = decltype(full_tag)::value;
+            uint32_t st = NT < 4 ? emit_head<L>(s, ptw, rkw(0)) : ptw;
+            // rounds 1..9 (+10), unrolled through a template parameter so that every window offset and
+            // flush bound is an immediate (a pragma-unrolled loop this large falls back to a runtime R)
+            auto step = [&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                if (NT < 4) st = round(WX::woff(R), WY::woff(R), WZ::woff(R), st, rkw(R));
+                if (R == 9 && NT < 4) {
+                    const uint32_t sub = emit_sbox<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), st, tab);
+                    const uint32_t sh = shift_rows(sub, quad_rot1(sub), quad_rot2(sub), quad_rot3(sub));
+                    st = emit_final_ark<L>(s, WX::woff(10), WY::woff(10), WZ::woff(10), sh, rkw(10));
+                }
+                wave_lds_fence();
+                if (R == 1) {
+                    AESW_TRACE_POINT(2);
+                    // a striding workgroup's next inputs travel while this group is flushed
+                    ptw_next = load_word(a.pt, grp + gridDim.x);
+                    if (PBK) kw_next = load_word(a.keys, grp + gridDim.x);
+                }
+                flush_round<L, NT, R, FULL>(lds, gx, gy, gz, sc, nvalid, lane);
+                wave_lds_fence();
+                if (R == 1) AESW_TRACE_POINT(3);
+                if (R == 5) AESW_TRACE_POINT(4);
+                if (R == 9) AESW_TRACE_POINT(5);
+            };
+            step(IntC<1>{}); step(IntC<2>{}); step(IntC<3>{}); step(IntC<4>{}); step(IntC<5>{});
+            step(IntC<6>{}); step(IntC<7>{}); step(IntC<8>{}); step(IntC<9>{});
+            return st;
         };
-        step(IntC<1>{}); step(IntC<2>{}); step(IntC<3>{}); step(IntC<4>{}); step(IntC<5>{});
-        step(IntC<6>{}); step(IntC<7>{}); step(IntC<8>{}); step(IntC<9>{});
+        const uint32_t st = nvalid == BPW ? chain(BoolC<true>{}) : chain(BoolC<false>{});
 
         if (a.ct && live) reinterpret_cast<uint32_t *>(a.ct)[(blk0 + blk) * 4 + w] = st;
     }
@@ -646,6 +689,8 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
     p.xcd_remap = xr ? 1u : 0u;
     const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
     const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KEMIT) + lds_pad;
+    // flush descriptors carry 16-bit LDS addresses: a group's staging must end below 64 KiB
+    if (TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KEMIT) > 65536 || !p0.ftab) return hipErrorInvalidValue;
     {
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&encrypt_kernel<L, XT, KM, KEMIT, NT>), lds);
         if (e != hipSuccess) return e;
@@ -657,8 +702,12 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
 
 template <int L, bool XT, int KM, bool KEMIT>
 static hipError_t launch_enc_nt(const EncParams &p, int waves, int nt, uint32_t cap, bool xr, uint32_t pad, hipStream_t s) {
-    return nt == 3 ? launch_enc<L, XT, KM, KEMIT, 3>(p, waves, cap, xr, pad, s)
-         : nt == 2 ? launch_enc<L, XT, KM, KEMIT, 2>(p, waves, cap, xr, pad, s)
+#ifdef AESW_DIAGNOSTIC
+    if (nt == 3) return launch_enc<L, XT, KM, KEMIT, 3>(p, waves, cap, xr, pad, s);
+    if (nt == 4) return launch_enc<L, XT, KM, KEMIT, 4>(p, waves, cap, xr, pad, s);
+    if (nt == 5) return launch_enc<L, XT, KM, KEMIT, 5>(p, waves, cap, xr, pad, s);
+#endif
+    return nt == 2 ? launch_enc<L, XT, KM, KEMIT, 2>(p, waves, cap, xr, pad, s)
          : nt == 1 ? launch_enc<L, XT, KM, KEMIT, 1>(p, waves, cap, xr, pad, s)
                    : launch_enc<L, XT, KM, KEMIT, 0>(p, waves, cap, xr, pad, s);
 }
@@ -674,7 +723,8 @@ hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, 
                           uint32_t max_groups_in_flight, bool xcd_remap, uint32_t pad, hipStream_t s) {
     if (waves < 1 || waves > 4 || keymode < 0 || keymode > 2) return hipErrorInvalidValue;
     const uint32_t cap = max_groups_in_flight;
-    const bool xr = xcd_remap && cap == 0;  // the remap assumes one workgroup per group
+    // a striding workgroup keeps its XCD class (id % 8) only when the stride is a multiple of 8
+    const bool xr = xcd_remap && (cap == 0 || cap % 8 == 0);
     if (layout == DENSE)
         return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, xr, pad, s)
                   : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, xr, pad, s);

@@ -115,7 +115,8 @@ template <int L> using WinZ = Win<Geo<L>::Z_HEAD, Geo<L>::Z_ROUND, Geo<L>::Z_TAI
 // line-aligned 16-block range) the lines that just became complete are
 // [lo, hi); piece (t, sub) is 16 bytes of line lo+t.  Returns where the piece
 // sits in the wave's LDS column stage (block windows of W::BYTES) and where it
-// goes in the wave's global range.  Shared by the kernel and the CPU lane model.
+// goes in the wave's global range.  This closed form is the SPECIFICATION (when a line leaves, from which LDS
+// bytes); the kernel runs the table-driven "scheduled flush" below, which the tests check against it.
 struct FlushPiece {
     bool ok;
     int lds_off;  // relative to the wave's stage of this column
@@ -158,53 +159,97 @@ AESW_HD FlushPiece flush_piece(int R, int b, int sub, int t, int nvalid) {
     return FlushPiece{ok, a + o + adj, P};
 }
 
-// The same flush in incremental form, the one the kernel runs: per column a lane keeps, for its
-// two blocks (passes h = 0, 1), base = b*GSTRIDE, a = b*BYTES and hi = the first line not flushed
-// yet.  Round R then flushes lines [hi_old, hi_new): no multiplications per round, ~10 VALU per
-// piece instead of ~18 (the flush address math was ~45 % of the kernel's VALU work and most of a
-// lone wave's latency).  flush_piece() above is the closed form; tests check they agree.
+// ---- scheduled flush (round 2) ---------------------------------------------------------------------------
+// The set of 128-byte lines of a wave's 16-block column range that complete in round R is the same for every full
+// wave: it only depends on the column geometry.  So the flush is a fixed schedule instead of per-round address
+// arithmetic: the lines of round R in address order, eight per store instruction (lane = (line slot lane>>3, 16-byte
+// piece lane&7)), and for every (instruction, lane) ONE descriptor word that says where the piece sits in the wave's
+// LDS stage and where it goes in the wave's global range.  The kernel loads its descriptors once (one dword per
+// lane and instruction, from a table the host builds with build_flush_table()) and keeps them in registers; a piece
+// then costs two VALU instructions instead of ~12, and ~55 instead of ~90 store instructions leave per wave.
+// flush_piece() above remains the specification of WHEN a line leaves and where its bytes are staged; the tests
+// check that the schedule stores every piece exactly once from the same LDS bytes.
+//   descriptor = lds_off | P << 16      lds_off: byte offset in the column's wave stage (the kernel adds the stage base;
+//                                        the sum must stay below 64 KiB), P: byte offset in the wave's global range;
+//   an unused slot has P = SCHED_INVALID_P (above any range), so "P < nvalid*GSTRIDE" is the store predicate of a
+//   partial wave and of a partial instruction alike.
+constexpr int SCHED_BPW = 16;
+constexpr uint32_t SCHED_INVALID_P = 0x7ff0u;
+
+// the round (1..9) whose flush carries block-relative byte o: the head leaves with round 1, round 10 with round 9
 template <class W>
-struct FlushState {
-    int base[2], a[2], hi[2];
-    bool valid[2], next_valid[2];
-    AESW_HD void init(int lane, int nvalid) {
-        for (int h = 0; h < 2; ++h) {
-            const int b = (lane >> 3) + 8 * h;
-            base[h] = b * W::GSTRIDE;
-            a[h] = b * W::BYTES;
-            hi[h] = (base[h] + 127) >> 7;  // first line that starts inside block b
-            valid[h] = b < nvalid;
-            next_valid[h] = b + 1 < nvalid;
-        }
+AESW_HD constexpr int sched_round_of(int o) {
+    for (int R = 1; R <= 8; ++R)
+        if (o < W::end(R)) return R;
+    return 9;
+}
+// the round in which line k of the wave's range is complete
+template <class W>
+AESW_HD constexpr int sched_line_round(int k) {
+    int r = 1;
+    for (int s = 0; s < 8; ++s) {
+        const int P = 128 * k + 16 * s, b = P / W::GSTRIDE, o = P - b * W::GSTRIDE;
+        const int q = sched_round_of<W>(o);
+        r = q > r ? q : r;
     }
-    // new upper bound after round R; call once per (round, pass) and keep the old value as lo
-    AESW_HD int advance(int R, int h) {
-        const int lo = hi[h];
-        const int nh = R == 9 ? (base[h] + W::GSTRIDE + 127) >> 7 : (base[h] + W::end(R)) >> 7;
-        hi[h] = nh < lo ? lo : nh;  // never below the first line that starts inside the block (see flush_piece)
-        return lo;
+    return r;
+}
+template <class W>
+AESW_HD constexpr int sched_nlines(int R) {
+    int n = 0;
+    for (int k = 0; k < SCHED_BPW * W::GSTRIDE / 128; ++k) n += sched_line_round<W>(k) == R ? 1 : 0;
+    return n;
+}
+template <class W> AESW_HD constexpr int sched_ninstr(int R) { return (sched_nlines<W>(R) + 7) / 8; }
+// index of round R's first instruction in the column's descriptor list; sched_first(10) = their total number
+template <class W>
+AESW_HD constexpr int sched_first(int R) {
+    int n = 0;
+    for (int r = 1; r < R; ++r) n += sched_ninstr<W>(r);
+    return n;
+}
+// where block-relative byte o is staged inside the block's window
+template <class W>
+AESW_HD constexpr int sched_window_offset(int o) {
+    if (o < W::HEAD) return o;
+    const int r = o >= W::start(10) ? 10 : (o - W::HEAD) / W::ROUND + 1;
+    return W::woff(r) + (o - W::start(r));
+}
+template <class W>
+AESW_HD constexpr uint32_t sched_descriptor(int R, int instr, int lane) {
+    const int slot = 8 * instr + (lane >> 3);
+    int seen = 0;
+    for (int k = 0; k < SCHED_BPW * W::GSTRIDE / 128; ++k) {
+        if (sched_line_round<W>(k) != R) continue;
+        if (seen++ != slot) continue;
+        const int P = 128 * k + 16 * (lane & 7), b = P / W::GSTRIDE, o = P - b * W::GSTRIDE;
+        return (uint32_t)(b * W::BYTES + sched_window_offset<W>(o)) | ((uint32_t)P << 16);
     }
-    AESW_HD FlushPiece piece(int R, int h, int lo, int sub, int t) const {
-        const int rmin = R - (W::NSLOT - 1) < 1 ? 1 : R - (W::NSLOT - 1);
-        const int k = lo + t;
-        const int P = 128 * k + 16 * sub;
-        int o = P - base[h];
-        int aa = a[h];
-        bool ok = k < hi[h] && valid[h];
-        int adj = W::woff(rmin) - W::start(rmin);
-        for (int r = rmin + 1; r <= R; ++r) adj = o >= W::start(r) ? W::woff(r) - W::start(r) : adj;
-        if (R == 9) {
-            adj = o >= W::start(10) ? W::woff(10) - W::start(10) : adj;
-            if (o >= W::GSTRIDE) {  // the next block's head; the wave's last block never gets here (its range ends on a line)
-                ok = ok && next_valid[h];
-                aa += W::BYTES;
-                o -= W::GSTRIDE;
-                adj = 0;
+    return SCHED_INVALID_P << 16;
+}
+// Pure host: the column's whole table, sched_first<W>(10) * 64 words, instruction-major (word i*64 + lane).
+template <class W>
+inline void build_flush_table(uint32_t *out) {
+    // one pass over the lines per round instead of sched_descriptor()'s search per entry
+    int line_round[SCHED_BPW * W::GSTRIDE / 128];
+    for (int k = 0; k < SCHED_BPW * W::GSTRIDE / 128; ++k) line_round[k] = sched_line_round<W>(k);
+    int idx = 0;
+    for (int R = 1; R <= 9; ++R) {
+        int lines[SCHED_BPW * W::GSTRIDE / 128], n = 0;
+        for (int k = 0; k < SCHED_BPW * W::GSTRIDE / 128; ++k)
+            if (line_round[k] == R) lines[n++] = k;
+        for (int i = 0; i < (n + 7) / 8; ++i, ++idx)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int slot = 8 * i + (lane >> 3);
+                uint32_t d = SCHED_INVALID_P << 16;
+                if (slot < n) {
+                    const int P = 128 * lines[slot] + 16 * (lane & 7), b = P / W::GSTRIDE, o = P - b * W::GSTRIDE;
+                    d = (uint32_t)(b * W::BYTES + sched_window_offset<W>(o)) | ((uint32_t)P << 16);
+                }
+                out[idx * 64 + lane] = d;
             }
-        }
-        return FlushPiece{ok, aa + o + adj, P};
     }
-};
+}
 
 // MixColumns matrix rows as the reference writes them (src/aes128.rs:228-233).
 constexpr int MIX[4][4] = {{2, 3, 1, 1}, {1, 2, 3, 1}, {1, 1, 2, 3}, {3, 1, 1, 2}};

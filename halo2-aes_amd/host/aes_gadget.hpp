@@ -31,40 +31,60 @@ enum class Tag : Fp { U8 = 1, Xor = 2, Sbox = 3, GfMul2 = 4, GfMul3 = 5 };
 constexpr uint64_t AES_ROWS_ = AESW_AES_ROWS;                    // src/constant.rs:114
 constexpr uint64_t KEY_SCHEDULE_ROWS_ = AESW_KEY_SCHEDULE_ROWS;  // src/constant.rs:113
 
-// The device-computed witness of one circuit: key slab + n encrypt slabs (dense
-// layout).  Computed once, read by every synthesize() pass (keygen_vk,
-// keygen_pk, create_proof all re-run synthesize: SURVEY 3.1).
+// The device-computed witness of one circuit: key slab + n encrypt slabs.  The
+// default layout is AESW_LAYOUT_PACKED (assigned cells only: nothing but live
+// cells crosses PCIe; aesw_layout_index maps a slab row to its byte);
+// AESW_LAYOUT_DENSE remains an option, AESW_LAYOUT_VALUES carries only what the
+// chips' value closures read.  Computed once, read by every synthesize() pass
+// (keygen_vk, keygen_pk, create_proof all re-run synthesize: SURVEY 3.1).
 struct AesWitness {
     uint64_t n = 0;
     uint8_t key[16] = {0};
     std::vector<uint8_t> pt;                        // n*16
-    std::vector<uint8_t> x, y, z;                   // dense: n*1360 each; values only: none / n*448 / n*608
-    std::vector<uint8_t> key_w, key_x, key_y, key_z;  // 96, 400, 400, 400
+    std::vector<uint8_t> x, y, z;                   // packed: n*1360 / n*1056 / n*608; dense: n*1360 each; values only: none / n*448 / n*608
+    std::vector<uint8_t> key_w, key_x, key_y, key_z;  // 96, then the key slab in the packed form (400 / 240 / 200) or dense (400 each)
+    int layout = AESW_LAYOUT_PACKED;
     bool values_only = false;                       // AESW_LAYOUT_VALUES: only what the chips' value closures read
     size_t sx = AES_ROWS_, sy = AES_ROWS_, sz = AES_ROWS_;  // bytes per block
-    int32_t iy[AESW_AES_ROWS], iz[AESW_AES_ROWS];   // values only: dense row -> index (-1: a copied cell)
+    int32_t iy[AESW_AES_ROWS], iz[AESW_AES_ROWS];   // slab row -> index in y / z (-1: the layout leaves the cell out)
+    int32_t kiy[AESW_KEY_ROWS], kiz[AESW_KEY_ROWS]; // the same for the key slab
     // The blocks currently readable: the whole batch, or -- streaming -- the chunk the device has just handed over
     // (aesw_encrypt_witness_stream: the next chunk's kernel and D2H are in flight while this one is assigned).
     mutable const uint8_t *vx = nullptr, *vy = nullptr, *vz = nullptr;
     mutable uint64_t vfirst = 0, vcount = 0;
 
     // aesw_schedule_key + aesw_encrypt_witness (host-pointer entry points).
+    // key slab of `layout` (VALUES keeps the packed key slab) + its row -> index maps
+    void schedule(aesw_ctx *ctx) {
+        const int kl = layout == AESW_LAYOUT_DENSE ? AESW_LAYOUT_DENSE : AESW_LAYOUT_PACKED;
+        if (kl == AESW_LAYOUT_DENSE) {
+            for (uint32_t r = 0; r < AESW_KEY_ROWS; ++r) kiy[r] = kiz[r] = (int32_t)r;
+        } else if (aesw_key_packed_index(1, kiy) != AESW_OK || aesw_key_packed_index(2, kiz) != AESW_OK) {
+            throw Error(Error::Synthesis, "aesw_key_packed_index failed");
+        }
+        key_w.resize(AESW_WORDS_ROWS);
+        key_x.resize(aesw_key_column_stride(kl, 0)); key_y.resize(aesw_key_column_stride(kl, 1)); key_z.resize(aesw_key_column_stride(kl, 2));
+        aesw_key_slab ks{key_w.data(), key_x.data(), key_y.data(), key_z.data()};
+        const int rc = aesw_schedule_key(ctx, key, kl, &ks);
+        if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("aesw_schedule_key: ") + aesw_strerror(rc));
+    }
+
     static std::shared_ptr<const AesWitness> generate(aesw_ctx *ctx, const uint8_t key[16], const uint8_t *pts, uint64_t n,
-                                                      bool values_only = false) {
+                                                      int layout = AESW_LAYOUT_PACKED) {
         auto w = std::make_shared<AesWitness>();
         w->n = n;
-        w->values_only = values_only;
+        w->layout = layout;
+        w->values_only = layout == AESW_LAYOUT_VALUES;
         std::memcpy(w->key, key, 16);
         w->pt.assign(pts, pts + 16 * n);
-        const int layout = values_only ? AESW_LAYOUT_VALUES : AESW_LAYOUT_DENSE;
         w->sx = aesw_column_stride(layout, 0); w->sy = aesw_column_stride(layout, 1); w->sz = aesw_column_stride(layout, 2);
+        if (!w->sy || !w->sz) throw Error(Error::Synthesis, "unknown witness layout");
         w->x.resize(n * w->sx); w->y.resize(n * w->sy); w->z.resize(n * w->sz);
         if (aesw_layout_index(layout, 1, w->iy) != AESW_OK || aesw_layout_index(layout, 2, w->iz) != AESW_OK)
             throw Error(Error::Synthesis, "aesw_layout_index failed");
-        w->key_w.resize(AESW_WORDS_ROWS); w->key_x.resize(AESW_KEY_ROWS); w->key_y.resize(AESW_KEY_ROWS); w->key_z.resize(AESW_KEY_ROWS);
-        aesw_key_slab ks{w->key_w.data(), w->key_x.data(), w->key_y.data(), w->key_z.data()};
-        int rc = aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks);
-        if (rc == AESW_OK && n)
+        w->schedule(ctx);
+        int rc = AESW_OK;
+        if (n)
             rc = aesw_encrypt_witness(ctx, pts, nullptr, 0, n, layout, w->sx ? w->x.data() : nullptr, w->y.data(), w->z.data(), nullptr, nullptr);
         if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("device witness generation failed: ") + aesw_strerror(rc));
         w->vx = w->sx ? w->x.data() : nullptr; w->vy = w->y.data(); w->vz = w->z.data();
@@ -77,16 +97,14 @@ struct AesWitness {
     static std::shared_ptr<const AesWitness> prepare_stream(aesw_ctx *ctx, const uint8_t key[16], const uint8_t *pts, uint64_t n) {
         auto w = std::make_shared<AesWitness>();
         w->n = n;
+        w->layout = AESW_LAYOUT_VALUES;
         w->values_only = true;
         std::memcpy(w->key, key, 16);
         w->pt.assign(pts, pts + 16 * n);
         w->sx = aesw_column_stride(AESW_LAYOUT_VALUES, 0); w->sy = aesw_column_stride(AESW_LAYOUT_VALUES, 1); w->sz = aesw_column_stride(AESW_LAYOUT_VALUES, 2);
         if (aesw_layout_index(AESW_LAYOUT_VALUES, 1, w->iy) != AESW_OK || aesw_layout_index(AESW_LAYOUT_VALUES, 2, w->iz) != AESW_OK)
             throw Error(Error::Synthesis, "aesw_layout_index failed");
-        w->key_w.resize(AESW_WORDS_ROWS); w->key_x.resize(AESW_KEY_ROWS); w->key_y.resize(AESW_KEY_ROWS); w->key_z.resize(AESW_KEY_ROWS);
-        aesw_key_slab ks{w->key_w.data(), w->key_x.data(), w->key_y.data(), w->key_z.data()};
-        const int rc = aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks);
-        if (rc != AESW_OK) throw Error(Error::Synthesis, std::string("aesw_schedule_key: ") + aesw_strerror(rc));
+        w->schedule(ctx);
         return w;
     }
     void stream(aesw_ctx *ctx, const std::function<void(uint64_t, uint64_t)> &assign) const {
@@ -109,24 +127,26 @@ struct AesWitness {
     }
 };
 
-// Where the gadget currently is inside a slab: three column arrays and a row.  With the values-only
-// witness (iy/iz set) x is absent and y holds only S-box / mul outputs: the copied cells have nothing
-// to be checked against, exactly as in the reference, where copy_advice() takes the source cell's value.
+// Where the gadget currently is inside a slab: three column arrays, the slab-row -> index maps of the
+// layout (column x has every row in the layouts that carry it) and a row.  With the values-only witness x is
+// absent and y holds only S-box / mul outputs: the copied cells have nothing to be checked against, exactly
+// as in the reference, where copy_advice() takes the source cell's value.
 struct WitnessCursor {
     const uint8_t *x = nullptr, *y = nullptr, *z = nullptr;
     uint64_t row = 0, rows = 0;
     const int32_t *iy = nullptr, *iz = nullptr;
     const uint8_t *pt = nullptr;  // the block's plaintext literal (src/aes128.rs:187), used when x is absent
-    uint8_t yv(uint64_t r) const { return iy ? y[iy[r]] : y[r]; }
-    uint8_t zv(uint64_t r) const { return iz ? z[iz[r]] : z[r]; }
+    uint8_t yv(uint64_t r) const { return y[iy[r]]; }
+    uint8_t zv(uint64_t r) const { return z[iz[r]]; }
     void expect_x(uint64_t r, Fp v, const char *what) const {
         // copy_advice carries the source cell's value; the device's x/y byte for the same cell must agree
         if (!x) return;
         if (r >= rows || x[r] != v) mismatch(what, r, r < rows ? x[r] : -1, v);
     }
     void expect_y(uint64_t r, Fp v, const char *what) const {
-        if (iy) return;
-        if (r >= rows || y[r] != v) mismatch(what, r, r < rows ? y[r] : -1, v);
+        if (r >= rows) mismatch(what, r, -1, v);
+        if (iy[r] < 0) return;  // values-only: the y cell of an xor row is not shipped
+        if (y[iy[r]] != v) mismatch(what, r, y[iy[r]], v);
     }
     [[noreturn]] void mismatch(const char *what, uint64_t r, int dev, Fp host) const {
         throw Error(Error::Mismatch, std::string("device witness disagrees with copied value: ") + what + " (slab row " + std::to_string(r) + " of " +
@@ -283,7 +303,7 @@ public:
     std::vector<std::vector<AssignedCell>> schedule_keys(Layouter &layouter, const uint8_t key[16]) {
         if (!wit) throw Error(Error::Synthesis, "no device witness attached");
         if (std::memcmp(key, wit->key, 16) != 0) throw Error(Error::Mismatch, "key differs from the key the device witness was generated for");
-        chip_cur = WitnessCursor{wit->key_x.data(), wit->key_y.data(), wit->key_z.data(), 0, AESW_KEY_ROWS};
+        chip_cur = WitnessCursor{wit->key_x.data(), wit->key_y.data(), wit->key_z.data(), 0, AESW_KEY_ROWS, wit->kiy, wit->kiz};
         words_row = 0;
         std::vector<std::vector<AssignedCell>> words;
         std::vector<AssignedCell> round = assign_first_round(layouter);
@@ -436,7 +456,7 @@ public:
         if (b < wit->vfirst || b >= wit->vfirst + wit->vcount) throw Error(Error::Mismatch, "encrypt() call outside the blocks the device has handed over");
         const uint64_t vb = b - wit->vfirst;
         cur = WitnessCursor{wit->vx ? wit->vx + vb * wit->sx : nullptr, wit->vy + vb * wit->sy, wit->vz + vb * wit->sz, 0, AES_ROWS_,
-                            wit->values_only ? wit->iy : nullptr, wit->values_only ? wit->iz : nullptr, wit->pt.data() + 16 * b};
+                            wit->iy, wit->iz, wit->pt.data() + 16 * b};
         if (bulk_assign && wit->values_only) throw Error(Error::Synthesis, "bulk assignment needs whole columns, not the values-only witness");
         if (bulk_assign && graph_ready) return encrypt_bulk(layouter);
         const size_t copies_before = layouter.copies().size();
@@ -513,9 +533,9 @@ private:
             for (uint64_t r = 0; r < AES_ROWS_; ++r) {
                 if (tags[r]) region.enable_selector(sel_of_tag[tags[r]], r);
                 cells[0][r] = region.assign_advice(adv[0], r, [c, r] { return Value::of(c->x[r]); }).cell;
-                if (pidx[1][r] >= 0) cells[1][r] = region.assign_advice(adv[1], r, [c, r] { return Value::of(c->y[r]); }).cell;
+                if (pidx[1][r] >= 0) cells[1][r] = region.assign_advice(adv[1], r, [c, r] { return Value::of(c->yv(r)); }).cell;
                 if (pidx[2][r] >= 0) {
-                    AssignedCell z = region.assign_advice(adv[2], r, [c, r] { return Value::of(c->z[r]); });
+                    AssignedCell z = region.assign_advice(adv[2], r, [c, r] { return Value::of(c->zv(r)); });
                     cells[2][r] = z.cell;
                     if (r >= AES_ROWS_ - 16) ct.push_back(z);
                 }

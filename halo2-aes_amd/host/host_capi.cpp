@@ -76,7 +76,7 @@ struct AesCircuit {
     std::vector<uint8_t> plaintexts;
     bool skip_schedule_key = false;
     bool bulk_assign = false;
-    bool values_only = false;  // the device hands over only what the chips' value closures read (AESW_LAYOUT_VALUES)
+    int layout = AESW_LAYOUT_PACKED;  // PACKED: assigned cells only (default); VALUES: only what the chips' value closures read; DENSE: option
     bool streaming = false;    // ... chunk by chunk, each chunk assigned while the next is produced and copied (configs[4])
     std::shared_ptr<const AesWitness> witness;  // computed lazily, once
     std::vector<std::vector<AssignedCell>> outputs;
@@ -86,7 +86,7 @@ struct AesCircuit {
         const uint64_t n = plaintexts.size() / 16;
         if (!witness)
             witness = streaming ? AesWitness::prepare_stream(ctx, key, plaintexts.data(), n)
-                                : AesWitness::generate(ctx, key, plaintexts.data(), n, values_only);
+                                : AesWitness::generate(ctx, key, plaintexts.data(), n, layout);
         config.attach_witness(witness);
         config.bulk_assign = bulk_assign;
         load_enc_full_table(layouter, config.tables, ctx);
@@ -165,11 +165,13 @@ const char *aesw_host_last_error(void) { return g_last_error.c_str(); }
 
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16], const uint8_t *pts, uint64_t n,
                               int with_witnesses, int skip_schedule_key, int assign_mode, aesw_host_circuit **out) {
-    if (!ctx || !key || (n && !pts) || !out || k < 11 || k > 26 || n_sets == 0 || n_sets > 64 || assign_mode < 0 || assign_mode > 3)
+    if (!ctx || !key || (n && !pts) || !out || k < 11 || k > 26 || n_sets == 0 || n_sets > 64 || assign_mode < 0 || assign_mode > 4)
         return AESW_ERR_INVALID_ARG;
     *out = nullptr;
     return guarded([&] {
-        AesCircuit circuit{ctx, k, n_sets, {0}, std::vector<uint8_t>(pts, pts + 16 * n), skip_schedule_key != 0, assign_mode == 1, assign_mode == 2, assign_mode == 3, nullptr, {}};
+        AesCircuit circuit{ctx, k, n_sets, {0}, std::vector<uint8_t>(pts, pts + 16 * n), skip_schedule_key != 0, assign_mode == 1,
+                           assign_mode == 2 || assign_mode == 3 ? AESW_LAYOUT_VALUES : assign_mode == 4 ? AESW_LAYOUT_DENSE : AESW_LAYOUT_PACKED,
+                           assign_mode == 3, nullptr, {}};
         std::memcpy(circuit.key, key, 16);
         auto *c = new aesw_host_circuit{MockProver::run(k, circuit, with_witnesses != 0), {}};
         c->outputs = std::move(circuit.outputs);
@@ -199,27 +201,26 @@ int aesw_host_aes_circuit_columns(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, co
         a.selectors.assign(p.cs.n_selectors, std::vector<uint8_t>(a.n_rows, 0));
         a.table.assign(p.cs.n_table, std::vector<uint8_t>(AESW_TABLE_ROWS, 0));
         auto chk = [](int rc, const char *what) { if (rc != AESW_OK) throw Error(Error::Synthesis, std::string(what) + ": " + aesw_strerror(rc)); };
-        // device witness, dense
-        std::vector<uint8_t> x(n * AESW_AES_ROWS), y(n * AESW_AES_ROWS), z(n * AESW_AES_ROWS);
-        std::vector<uint8_t> kw(AESW_WORDS_ROWS), kx(AESW_KEY_ROWS), ky(AESW_KEY_ROWS), kz(AESW_KEY_ROWS);
+        // device witness, packed: only assigned cells cross PCIe; aesw_packed_index places them
+        const int L = AESW_LAYOUT_PACKED;
+        const size_t cs[3] = {aesw_column_stride(L, 0), aesw_column_stride(L, 1), aesw_column_stride(L, 2)};
+        std::vector<uint8_t> x(n * cs[0]), y(n * cs[1]), z(n * cs[2]);
+        std::vector<uint8_t> kw(AESW_WORDS_ROWS), kx(aesw_key_column_stride(L, 0)), ky(aesw_key_column_stride(L, 1)), kz(aesw_key_column_stride(L, 2));
         aesw_key_slab ks{kw.data(), kx.data(), ky.data(), kz.data()};
-        chk(aesw_schedule_key(ctx, key, AESW_LAYOUT_DENSE, &ks), "aesw_schedule_key");
-        if (n) chk(aesw_encrypt_witness(ctx, pts, nullptr, 0, n, AESW_LAYOUT_DENSE, x.data(), y.data(), z.data(), nullptr, nullptr), "aesw_encrypt_witness");
+        chk(aesw_schedule_key(ctx, key, L, &ks), "aesw_schedule_key");
+        if (n) chk(aesw_encrypt_witness(ctx, pts, nullptr, 0, n, L, x.data(), y.data(), z.data(), nullptr, nullptr), "aesw_encrypt_witness");
         chk(aesw_lookup_table(ctx, a.table[0].data(), a.table[1].data(), a.table[2].data(), a.table[3].data()), "aesw_lookup_table");
         // advice columns
         const uint32_t words_col = 3 * n_sets;
-        uint8_t em[3][AESW_AES_ROWS], km[3][AESW_KEY_ROWS];  // which cells the reference assigns at all
+        int32_t ei[3][AESW_AES_ROWS], ki[3][AESW_KEY_ROWS];  // slab row -> packed index; -1 = a cell the reference never assigns
         for (int j = 0; j < 3; ++j) {
-            int32_t ei[AESW_AES_ROWS], ki[AESW_KEY_ROWS];
-            chk(aesw_packed_index(j, ei), "aesw_packed_index");
-            chk(aesw_key_packed_index(j, ki), "aesw_key_packed_index");
-            for (uint32_t r = 0; r < AESW_AES_ROWS; ++r) em[j][r] = ei[r] >= 0;
-            for (uint32_t r = 0; r < AESW_KEY_ROWS; ++r) km[j][r] = ki[r] >= 0;
+            chk(aesw_packed_index(j, ei[j]), "aesw_packed_index");
+            chk(aesw_key_packed_index(j, ki[j]), "aesw_key_packed_index");
         }
         const uint8_t *kcols[3] = {kx.data(), ky.data(), kz.data()};
         for (int j = 0; j < 3; ++j)
             for (uint32_t r = 0; r < AESW_KEY_ROWS; ++r)
-                if (km[j][r]) { a.advice[j][r] = kcols[j][r]; a.advice_assigned[j][r] = 1; }
+                if (ki[j][r] >= 0) { a.advice[j][r] = kcols[j][ki[j][r]]; a.advice_assigned[j][r] = 1; }
         for (uint32_t r = 0; r < AESW_WORDS_ROWS; ++r) { a.advice[words_col][r] = kw[r]; a.advice_assigned[words_col][r] = 1; }
         std::vector<uint32_t> bset(n);
         std::vector<uint64_t> brow(n);
@@ -228,9 +229,9 @@ int aesw_host_aes_circuit_columns(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, co
             chk(aesw_block_placement(k, n_sets, b, &bset[b], &brow[b]), "aesw_block_placement");
             for (int j = 0; j < 3; ++j) {
                 uint8_t *dst = a.advice[3 * bset[b] + j].data() + brow[b], *asg = a.advice_assigned[3 * bset[b] + j].data() + brow[b];
-                const uint8_t *src = cols[j] + b * AESW_AES_ROWS;
+                const uint8_t *src = cols[j] + b * cs[j];
                 for (uint32_t r = 0; r < AESW_AES_ROWS; ++r)
-                    if (em[j][r]) { dst[r] = src[r]; asg[r] = 1; }
+                    if (ei[j][r] >= 0) { dst[r] = src[ei[j][r]]; asg[r] = 1; }
             }
         }
         // selectors + fixed column

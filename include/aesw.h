@@ -75,7 +75,8 @@ enum aesw_status {
     AESW_ERR_CAPACITY = 5,  /* the reference panics: "AES calls too many" src/aes128.rs:160-162 */
     AESW_ERR_NO_KEY = 6,    /* the reference panics: "Keys should be scheduled" src/aes128.rs:170 */
     AESW_ERR_MISMATCH = 7,  /* host value disagrees with the device witness (Error::Synthesis) */
-    AESW_ERR_UNSATISFIED = 8
+    AESW_ERR_UNSATISFIED = 8,
+    AESW_ERR_COMM = 9       /* RCCL is missing or a collective call failed; see aesw_comm_last_error() */
 };
 
 enum aesw_layout { AESW_LAYOUT_DENSE = 0, AESW_LAYOUT_PACKED = 1, AESW_LAYOUT_VALUES = 2 };
@@ -227,6 +228,39 @@ int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, in
 /* host-pointer aesw_schedule_key_device: key is 16 host bytes, key_slab host buffers (optional) */
 int aesw_schedule_key(aesw_ctx *ctx, const uint8_t key[16], int layout, const aesw_key_slab *key_slab);
 int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3);
+
+/* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) -------------- */
+/* Blocks shard by contiguous index range and need no collective to be generated
+ * (SURVEY 8(e)); handing the whole witness to one consumer is ONE gather: every
+ * rank's range of a column is a contiguous byte range of the gathered column
+ * (BASELINE configs[3]).  The reference has no counterpart (single process).
+ * aesw_comm_unique_id: called by one rank; the host carries the 128 bytes to
+ * the others (MPI, a socket, ...).  aesw_comm_create is collective over the
+ * nranks processes (ncclCommInitRank); rank r drives the device of its ctx.
+ * A communicator with nranks = 1 needs no RCCL at all. */
+#define AESW_COMM_ID_BYTES 128u
+typedef struct aesw_comm aesw_comm;
+int aesw_comm_unique_id(uint8_t id[AESW_COMM_ID_BYTES]);
+int aesw_comm_create(aesw_ctx *ctx, int nranks, int rank, const uint8_t id[AESW_COMM_ID_BYTES],
+                     aesw_comm **out);
+void aesw_comm_destroy(aesw_comm *comm);
+/* Largest single send/recv in bytes (default 1 GiB): a rank's range of one column travels in pieces. */
+int aesw_comm_set_max_message(aesw_comm *comm, uint64_t bytes);
+/* Text of the last communicator failure on this thread ("" if none). */
+const char *aesw_comm_last_error(void);
+/* Pure host: offsets[r] = blocks before rank r's range in the gathered columns, *total = all blocks. */
+int aesw_gather_offsets(int nranks, const uint64_t *counts, uint64_t *offsets, uint64_t *total);
+/* Gather n_cols columns on `root`, asynchronously on `stream` (so it is ordered
+ * behind the kernels that produced the columns on that stream): rank r sends
+ * counts[r] * strides[c] bytes of d_send[c]; the root receives rank r's range at
+ * d_recv[c] + offsets[r] * strides[c] (its own range is copied device-to-device,
+ * or left alone when d_send[c] already points there).  All sends and receives
+ * are issued inside one ncclGroupStart/End, so the peers' transfers -- each over
+ * its own xGMI link to the root -- run concurrently.  d_recv is read on the root
+ * only.  counts has nranks entries on every rank. */
+int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint8_t *const *d_send,
+                               uint8_t *const *d_recv, const uint64_t *counts,
+                               const uint32_t *strides, void *stream);
 
 /* ---- tuning / introspection (bench.py, tests) ----------------------------- */
 /* name: "waves_shared" / "waves_pbk" (waves per group, 0 = auto, 1..4),

@@ -29,6 +29,8 @@ typedef struct aesw_host_circuit aesw_host_circuit;
  * FixedAes128Config<K, n_sets> circuit of 2^k rows.  with_witnesses = 0 mimics
  * keygen (value closures are never evaluated).  skip_schedule_key = 1 omits
  * schedule_key() to exercise the reference's expect("Keys should be scheduled").
+ * The device witness travels in AESW_LAYOUT_PACKED (assigned cells only;
+ * aesw_layout_index places them) unless a mode below says otherwise.
  * assign_mode = 1 (bulk): the first block goes through the reference's 1 360
  * one-row regions, every later block is assigned as ONE 1 360-row region that
  * replays the first block's copy graph; cells, selectors and
@@ -39,7 +41,9 @@ typedef struct aesw_host_circuit aesw_host_circuit;
  * copy_advice(), as in the reference.
  * assign_mode = 3 (streaming, BASELINE configs[4]): as 2, but the witness arrives
  * through aesw_encrypt_witness_stream: encrypt() calls of chunk i run while the
- * device produces chunk i+1 and copies it to the host. */
+ * device produces chunk i+1 and copies it to the host.
+ * assign_mode = 4: as 0 with the AESW_LAYOUT_DENSE witness (an exact image of
+ * the advice rows; 35 % of it is zeros for never-assigned cells). */
 int aesw_host_aes_circuit_run(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, const uint8_t key[16],
                               const uint8_t *pts, uint64_t n, int with_witnesses,
                               int skip_schedule_key, int assign_mode, aesw_host_circuit **out);

@@ -1,6 +1,6 @@
 // lane_model.cpp -- CPU execution of the device program's shared source:
 // the per-lane code (halo2-aes_amd/csrc/aesw_lane.h), the staging windows and
-// the whole-line flush index math (aesw_layout.h), wave by wave (16 blocks),
+// the scheduled whole-line flush (aesw_layout.h: descriptor table), wave by wave (16 blocks),
 // with the cross-lane steps (DPP quad permutes) and LDS replaced by arrays.
 // TEST INFRASTRUCTURE: lets `-m "not gpu"` tests compare the device program
 // with the oracle before any GPU run.  Not reachable from the product library.
@@ -39,39 +39,49 @@ struct HostKSink {
 
 uint32_t ld32(const uint8_t *p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
 
-// One column's flush after round R for the whole wave, with the kernel's incremental FlushState
-// (states[lane] carried from round to round).
+// One column's flush after round R for the whole wave, as the kernel runs it: the host-built descriptor table
+// (build_flush_table), instruction by instruction, every lane storing its 16-byte piece when "offset < nvalid*stride".
 template <class W>
-void flush_col(int R, const std::vector<uint8_t> &stage, uint8_t *g, std::vector<FlushState<W>> &states) {
-    for (int lane = 0; lane < 64; ++lane)
-        for (int h = 0; h < 2; ++h) {
-            const int lo = states[lane].advance(R, h);
-            for (int t = 0; t < flush_maxc<W>(R); ++t) {
-                const FlushPiece fp = states[lane].piece(R, h, lo, lane & 7, t);
-                if (fp.ok) std::memcpy(g + fp.P, stage.data() + fp.lds_off, 16);
-            }
+struct ColTable {
+    std::vector<uint32_t> t;
+    ColTable() : t((size_t)sched_first<W>(10) * 64) { build_flush_table<W>(t.data()); }
+};
+
+template <class W>
+void flush_col(int R, const std::vector<uint8_t> &stage, uint8_t *g, const ColTable<W> &tab, int nvalid) {
+    const uint32_t limit = (uint32_t)nvalid * W::GSTRIDE;
+    for (int i = sched_first<W>(R); i < sched_first<W>(R + 1); ++i)
+        for (int lane = 0; lane < 64; ++lane) {
+            const uint32_t d = tab.t[(size_t)i * 64 + lane], off = d >> 16;
+            if (off < limit) std::memcpy(g + off, stage.data() + (d & 0xffffu), 16);
         }
 }
 
-// FlushState (incremental) against flush_piece (closed form) for every round, lane, piece and
-// number of valid blocks: returns the number of disagreements on stored pieces.
+// The scheduled flush against flush_piece (the closed-form specification) for every round and number of valid
+// blocks: the same pieces leave in the same round from the same LDS bytes.  Returns the number of disagreements.
 template <class W>
 int flush_forms_disagree() {
     int bad = 0;
-    for (int nvalid = 1; nvalid <= BPW; ++nvalid)
-        for (int lane = 0; lane < 64; ++lane) {
-            FlushState<W> st;
-            st.init(lane, nvalid);
-            for (int R = 1; R <= 9; ++R)
-                for (int h = 0; h < 2; ++h) {
-                    const int lo = st.advance(R, h);
+    const ColTable<W> tab;
+    const int npieces = BPW * W::GSTRIDE / 16;
+    for (int nvalid = 1; nvalid <= BPW; ++nvalid) {
+        std::vector<int> spec(npieces, -1), got(npieces, -1);  // piece -> lds_off | round << 20
+        for (int R = 1; R <= 9; ++R)
+            for (int b = 0; b < BPW; ++b)
+                for (int sub = 0; sub < 8; ++sub)
                     for (int t = 0; t < flush_maxc<W>(R); ++t) {
-                        const FlushPiece a = st.piece(R, h, lo, lane & 7, t);
-                        const FlushPiece b = flush_piece<W>(R, (lane >> 3) + 8 * h, lane & 7, t, nvalid);
-                        if (a.ok != b.ok || (a.ok && (a.lds_off != b.lds_off || a.P != b.P))) bad++;
+                        const FlushPiece fp = flush_piece<W>(R, b, sub, t, nvalid);
+                        if (fp.ok) spec[fp.P / 16] = fp.lds_off | (R << 20);
                     }
+        for (int R = 1; R <= 9; ++R)
+            for (int i = sched_first<W>(R); i < sched_first<W>(R + 1); ++i)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const uint32_t d = tab.t[(size_t)i * 64 + lane], off = d >> 16;
+                    if (off < (uint32_t)nvalid * W::GSTRIDE) got[off / 16] = (int)(d & 0xffffu) | (R << 20);
+                    if (d != sched_descriptor<W>(R, i - sched_first<W>(R), lane)) bad++;  // table == constexpr form
                 }
-        }
+        for (int p = 0; p < npieces; ++p) bad += spec[p] != got[p];
+    }
     return bad;
 }
 
@@ -81,20 +91,11 @@ int flush_forms_disagree() {
 template <class W>
 int flush_not_exactly_once() {
     int bad = 0;
+    const ColTable<W> tab;
     for (int nvalid = 1; nvalid <= BPW; ++nvalid) {
         std::vector<int> seen((size_t)BPW * W::GSTRIDE / 16, 0);
-        for (int lane = 0; lane < 64; ++lane) {
-            FlushState<W> st;
-            st.init(lane, nvalid);
-            for (int R = 1; R <= 9; ++R)
-                for (int h = 0; h < 2; ++h) {
-                    const int lo = st.advance(R, h);
-                    for (int t = 0; t < flush_maxc<W>(R); ++t) {
-                        const FlushPiece fp = st.piece(R, h, lo, lane & 7, t);
-                        if (fp.ok) seen[fp.P / 16]++;
-                    }
-                }
-        }
+        for (uint32_t d : tab.t)
+            if ((d >> 16) < (uint32_t)nvalid * W::GSTRIDE) seen[(d >> 16) / 16]++;
         for (size_t i = 0; i < seen.size(); ++i) bad += seen[i] != ((int)i < nvalid * W::GSTRIDE / 16 ? 1 : 0);
     }
     return bad;
@@ -149,10 +150,9 @@ void run(const uint8_t *tab, const uint8_t *pt, const uint8_t *keys, int per_blo
                 st[b][w] = emit_head<L>(s, ptw, rk[b * 44 + w]);
             }
         uint8_t *gx = x + (size_t)G::XS * blk0, *gy = y + (size_t)G::YS * blk0, *gz = z + (size_t)G::ZS * blk0;
-        std::vector<FlushState<WX>> fx(64);
-        std::vector<FlushState<WY>> fy(64);
-        std::vector<FlushState<WZ>> fz(64);
-        for (int lane = 0; lane < 64; ++lane) { fx[lane].init(lane, nvalid); fy[lane].init(lane, nvalid); fz[lane].init(lane, nvalid); }
+        static const ColTable<WX> fx;
+        static const ColTable<WY> fy;
+        static const ColTable<WZ> fz;
         for (int R = 1; R <= 9; ++R) {
             for (int b = 0; b < BPW; ++b) {
                 for (int w = 0; w < 4; ++w) { auto s = sink(b, w); sub[w] = emit_sbox<L>(s, WX::woff(R), WY::woff(R), WZ::woff(R), st[b][w], T); }
@@ -168,9 +168,9 @@ void run(const uint8_t *tab, const uint8_t *pt, const uint8_t *keys, int per_blo
                     }
                 }
             }
-            if (G::HAS_X) flush_col<WX>(R, sx, gx, fx);
-            flush_col<WY>(R, sy, gy, fy);
-            flush_col<WZ>(R, sz, gz, fz);
+            if (G::HAS_X) flush_col<WX>(R, sx, gx, fx, nvalid);
+            flush_col<WY>(R, sy, gy, fy, nvalid);
+            flush_col<WZ>(R, sz, gz, fz, nvalid);
         }
     }
 }

@@ -30,7 +30,23 @@ def test_every_declared_symbol_is_exported(pkg):
     assert sorted(pkg.api.HOST_SYMBOLS) == host_names, "api.py binds a different set than include/aesw_host.h declares"
     out = subprocess.run(["nm", "-D", "--defined-only", str(pkg.api.LIB_PATH)], stdout=subprocess.PIPE, text=True).stdout
     exported = set(re.findall(r" T (aesw_\w+)", out))
-    assert set(names) <= exported and set(host_names) <= exported
+    assert set(names) <= exported
+    # the device library carries no host-mirror code: that lives in libaesw_host.so, above the C ABI
+    assert not any(n.startswith("aesw_host_") and n not in ("aesw_host_alloc", "aesw_host_free") for n in exported)
+    hlib = pkg.api.load_host_library()
+    for n in host_names:
+        assert hasattr(hlib, n), "libaesw_host.so does not export %s" % n
+    out = subprocess.run(["nm", "-D", "--defined-only", str(pkg.api.HOST_LIB_PATH)], stdout=subprocess.PIPE, text=True).stdout
+    assert set(host_names) <= set(re.findall(r" T (aesw_\w+)", out))
+    assert b"gfx950" not in pkg.api.HOST_LIB_PATH.read_bytes()   # host code only
+
+
+def test_no_diagnostic_kernels_in_the_product(pkg):
+    """The "leave the flush out" (store_mode 3) instantiations exist only in -DAESW_DIAGNOSTIC builds."""
+    out = subprocess.run(["nm", "-C", str(pkg.api.LIB_PATH)], stdout=subprocess.PIPE, text=True).stdout
+    enc = [l for l in out.splitlines() if "encrypt_kernel<" in l]
+    assert enc, "no encrypt_kernel symbols found"
+    assert not any(re.search(r"encrypt_kernel<[^>]*, 3>", l) for l in enc)
 
 
 def test_library_is_gfx950_code(pkg):

@@ -126,7 +126,7 @@ def test_window_geometry(model):
 
 
 def test_flush_incremental_equals_closed_form(model):
-    """The kernel's incremental flush index math (FlushState) == the closed form (flush_piece) for every
+    """The kernel's scheduled flush (descriptor table) == the closed form (flush_piece) for every
     round, lane, piece and number of valid blocks, in all six column geometries."""
     assert model.lane_model_flush_forms_disagree() == 0
 

@@ -12,7 +12,10 @@ import __graft_entry__ as ge  # noqa: E402
 ge.build()
 pkg = ge.load_package()
 import bench  # noqa: E402
-other = pkg.api.load_library(Path(sys.argv[1]).resolve())
+other = C.CDLL(str(Path(sys.argv[1]).resolve()))  # an older build may lack newer symbols: bind only what this tool calls
+for name in ("aesw_create", "aesw_schedule_key_device", "aesw_encrypt_witness_device", "aesw_last_error", "aesw_set_option"):
+    res, args = pkg.api.SYMBOLS[name]
+    getattr(other, name).restype, getattr(other, name).argtypes = res, args
 workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 log2n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 layout = {"packed": pkg.LAYOUT_PACKED, "dense": pkg.LAYOUT_DENSE, "values": pkg.LAYOUT_VALUES}[sys.argv[4] if len(sys.argv) > 4 else "packed"]
