@@ -5,16 +5,24 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N>1 is launched by torch.distributed.run, one rank per GPU.
 A "step" is one pass of the hot path over one batch of synthetic input that is
 already resident in HBM: one aesw_encrypt_witness_device launch over
-BASELINE.json configs[1] -- 2^16 blocks, one shared key, 1 MI355X -- per rank
-(weak scaling: every rank generates its own 2^16-block shard, no collective on
-the data path; see halo2-aes_amd/sharding.py).  Rank 0 prints ONE JSON line.
+BASELINE.json configs[2] -- 2^20 blocks, per-block keys (the GPU key-schedule
+path, src/key_schedule.rs:80-224) with the key-schedule witness, packed advice
+columns, 1 MI355X -- per rank (weak scaling: every rank generates its own
+2^20-block shard, no collective on the data path; halo2-aes_amd/sharding.py).
+Rank 0 prints ONE JSON line.
 
-roofline.achieved = algorithmic bytes per launch (3040 B/block shared key,
-3992 B/block per-block keys: SURVEY.md 8(d)) / average launch
-duration measured here with HIP events on the launch stream.
+Timed region: the K steps are captured in ONE hipGraph; after W untimed warm-up
+steps the graph is replayed REPLAYS times, each replay bracketed by barrier +
+synchronize and timed on its own (wall clock and HIP events on the launch
+stream).  `value` and `ms_per_step` come from the MEDIAN replay (exactly K
+steps); every replay, min and max are in `timing`.
+
+roofline.achieved = algorithmic bytes per launch (3992 B/block per-block keys,
+3040 B/block shared key: SURVEY.md 8(d)) / mean launch duration of
+the median replay from HIP events; frac_events and frac_wall are both given.
 cpu_baseline = the CPU oracle (a port of the reference's value path, NOT the
 reference: Rust + halo2 cannot be built here) timed on this box's host cores on
-a bounded sample, N=1 only.
+a bounded sample of the same workload shape, N=1 only.
 """
 from __future__ import annotations
 
@@ -22,7 +30,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -35,19 +45,22 @@ BYTES_SHARED = 3040     # 3024 live cells written + 16 B plaintext read per bloc
 BYTES_PBK = 3992        # + 936 key-schedule cells + 16 B key read per block
 BYTES_VALUES = 1072     # AESW_LAYOUT_VALUES: 448 + 608 closure-computed cells written + 16 B read per block
 SEED = 0xA35128
+REPLAYS = 5
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--layout", choices=["packed", "dense", "values"], default="packed")
-    ap.add_argument("--workload", choices=["c1", "c2"], default="c1",
-                    help="c1 = 2^16 blocks shared key (BASELINE configs[1]); c2 = 2^20 blocks per-block keys")
+    ap.add_argument("--workload", choices=["c1", "c2"], default="c2",
+                    help="c2 = 2^20 blocks per-block keys + key witness (BASELINE configs[2], the headline); c1 = 2^16 blocks shared key (configs[1])")
     ap.add_argument("--log2-blocks", type=int, default=None, help="override the batch size (per rank)")
+    ap.add_argument("--replays", type=int, default=REPLAYS, help="timed replays of the K-step graph (median reported)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--c3-log2-blocks", type=int, default=None, help="N>1 extra: blocks per GPU of the configs[3] run (default 21)")
+    ap.add_argument("--c4-log2-blocks", type=int, default=24, help="N=1 extra: blocks of the configs[4] streaming run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of a hipGraph")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to aesw_set_option")
@@ -81,6 +94,8 @@ class Runner:
         self.bytes_per_block = BYTES_PBK if (per_block_keys and key_slab) else BYTES_SHARED
         if layout == pkg.LAYOUT_VALUES:  # only closure-computed cells: 448 + 608 B written, 16 B read per block
             self.bytes_per_block = BYTES_VALUES + (936 + 16 if (per_block_keys and key_slab) else 0)
+        self.graph = None
+        self.graph_steps = 0
 
     def launch(self, i, stream):
         s = self.sets[i % self.nsets]
@@ -91,18 +106,17 @@ class Runner:
         if rc:
             raise RuntimeError("aesw_encrypt_witness_device rc=%d %s" % (rc, self.lib.aesw_last_error(self.h).decode()))
 
-    def run(self, steps, warmup, use_graph, barrier=None):
-        """Returns (wall seconds for `steps` steps, mean launch duration in ms from HIP events)."""
+    def prepare(self, steps, warmup, use_graph):
+        """W untimed warm-up steps, then (optionally) one hipGraph holding all K launches."""
         torch = self.torch
         stream = torch.cuda.current_stream()
         sp = C.c_void_p(stream.cuda_stream)
         for i in range(warmup):
             self.launch(i, sp)
         torch.cuda.synchronize()
-        graph = None
+        self.graph, self.graph_steps = None, steps
         if use_graph:
             try:
-                # one hipGraph holding all K launches: no per-step host work in the timed region
                 cap = torch.cuda.Stream()
                 cap.wait_stream(stream)
                 graph = torch.cuda.CUDAGraph()
@@ -112,19 +126,26 @@ class Runner:
                         self.launch(i, csp)
                 graph.replay()  # untimed: instantiate / upload
                 torch.cuda.synchronize()
+                self.graph = graph
             except Exception as e:  # pragma: no cover - depends on the runtime
                 print("bench: hipGraph capture unavailable (%s); launching from the host" % e, file=sys.stderr)
-                graph = None
+                self.graph = None
+
+    def timed(self, barrier=None):
+        """EXACTLY K steps between barrier + synchronize on both sides.
+        Returns (wall seconds, mean launch duration in ms from HIP events on the launch stream)."""
+        torch = self.torch
+        sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if barrier:
             barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e0.record()
-        if graph is not None:
-            graph.replay()
+        if self.graph is not None:
+            self.graph.replay()
         else:
-            for i in range(steps):
+            for i in range(self.graph_steps):
                 self.launch(i, sp)
         e1.record()
         while not e1.query():  # poll: a blocking wait adds its wake-up latency to a short timed region
@@ -133,36 +154,73 @@ class Runner:
         t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks is taken by the caller
         if barrier:
             barrier()
-        return t1 - t0, e0.elapsed_time(e1) / steps, graph is not None
+        return t1 - t0, e0.elapsed_time(e1) / self.graph_steps
+
+    def run(self, steps, warmup, use_graph, barrier=None):
+        """One timed region (tools/ and the extras): (wall seconds, mean launch ms, graphed)."""
+        self.prepare(steps, warmup, use_graph)
+        wall, ms = self.timed(barrier)
+        return wall, ms, self.graph is not None
 
 
-def cpu_baseline(n_target_seconds=12.0):
+def cpu_baseline(per_block_keys, n_target_seconds=12.0):
     """The CPU oracle on this host's cores: 1 thread (the reference synthesizes
-    single-threaded) on a bounded sample of the same workload shape."""
+    single-threaded) on a bounded sample of the headline workload's shape."""
     import numpy as np
     import oracle_lib
     orc = oracle_lib.Oracle()
-    rng = np.random.default_rng(SEED + 1)
+    rng = np.random.default_rng(SEED + 2)
+
+    def once(pt, keys, threads):
+        t0 = time.perf_counter()
+        orc.encrypt_witness(pt, keys, layout=oracle_lib.PACKED, threads=threads)
+        if per_block_keys:  # the key-schedule witness of every block's key (src/key_schedule.rs:80-224)
+            orc.key_schedule_witness(keys, layout=oracle_lib.PACKED, threads=threads)
+        return time.perf_counter() - t0
+
+    def inputs(n):
+        return (rng.integers(0, 256, (n, 16), dtype=np.uint8),
+                rng.integers(0, 256, (n, 16) if per_block_keys else 16, dtype=np.uint8))
+
     probe = 2048
-    pt = rng.integers(0, 256, (probe, 16), dtype=np.uint8)
-    key = rng.integers(0, 256, 16, dtype=np.uint8)
-    t0 = time.perf_counter()
-    orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=1)
-    rate = probe / (time.perf_counter() - t0)
+    rate = probe / once(*inputs(probe), 1)
     n = int(max(4096, min(1 << 20, rate * n_target_seconds)))
-    pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
-    t0 = time.perf_counter()
-    orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=1)
-    dt1 = time.perf_counter() - t0
+    pt, keys = inputs(n)
+    dt1 = once(pt, keys, 1)
     cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    orc.encrypt_witness(pt, key, layout=oracle_lib.PACKED, threads=cores)
-    dtn = time.perf_counter() - t0
+    dtn = once(pt, keys, cores)
     return {
         "value": n / dt1, "unit": "blocks/s", "cores": 1, "kind": "port",
-        "sample": "%d blocks, shared key, packed layout, oracle/aesw_oracle.c single thread (%.1f s)" % (n, dt1),
+        "sample": "%d blocks, %s, packed layout, oracle/aesw_oracle.c single thread (%.1f s)" % (
+            n, "per-block keys + key-schedule witness" if per_block_keys else "shared key", dt1),
         "all_cores": {"value": n / dtn, "cores": cores},
     }
+
+
+class Watchdog:
+    """A stalled collective must not look like success: each phase of the N>1 tail gets its own budget; on expiry
+    rank 0 prints the line with the phase that stalled and EVERY rank exits non-zero."""
+
+    def __init__(self, rank, line):
+        self.rank, self.line, self.timer, self.phase = rank, line, None, None
+
+    def arm(self, phase, seconds):
+        self.disarm()
+        self.phase = phase
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _fire(self):
+        if self.rank == 0:
+            self.line["error"] = "phase '%s' timed out" % self.phase
+            print(json.dumps(self.line), flush=True)
+        os._exit(3)
 
 
 def main():
@@ -201,7 +259,7 @@ def main():
     layout = {"packed": pkg.LAYOUT_PACKED, "dense": pkg.LAYOUT_DENSE, "values": pkg.LAYOUT_VALUES}[a.layout]
     host_bufs = None
     if rank == 0 and dist is None and not a.no_extras:
-        # Page-locked buffers of the PCIe-inclusive extra are taken first, as a host would at start-up.
+        # Page-locked buffers of the PCIe-inclusive extras are taken first, as a host would at start-up.
         try:
             nn_host = 1 << 20
             host_bufs = (pkg.api.host_alloc(nn_host * 16).reshape(nn_host, 16),
@@ -213,29 +271,36 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if a.workload == "c1":
-        n = 1 << (a.log2_blocks or 16)
-        runner = Runner(pkg, ctx, torch, n, False, layout, False, SEED + 1 + rank)
-        wl = "2^%d blocks, one shared key, %s advice columns" % (a.log2_blocks or 16, a.layout)
-    else:
-        n = 1 << (a.log2_blocks or 20)
-        runner = Runner(pkg, ctx, torch, n, True, layout, True, SEED + 2 + rank)
-        wl = "2^%d blocks, per-block keys (+ key-schedule witness), %s advice columns" % (a.log2_blocks or 20, a.layout)
-    wall, ms_launch, graphed = runner.run(a.steps, a.warmup, not a.no_graph, barrier)
-    if dist is not None:
-        t = torch.tensor([wall, ms_launch], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, ms_launch = float(t[0]), float(t[1])
+    pbk = a.workload == "c2"
+    lg = a.log2_blocks or (20 if pbk else 16)
+    n = 1 << lg
+    # the per-rank workload at N>1 IS the N=1 headline workload, so the driver's 1/2/4/8 curve compares like with like
+    runner = Runner(pkg, ctx, torch, n, pbk, layout, pbk, SEED + (2 if pbk else 1) + rank)
+    wl = ("2^%d blocks, per-block keys (+ key-schedule witness), %s advice columns (BASELINE configs[2])" if pbk else
+          "2^%d blocks, one shared key, %s advice columns (BASELINE configs[1])") % (lg, a.layout)
+    runner.prepare(a.steps, a.warmup, not a.no_graph)
+    graphed = runner.graph is not None
+    replays = []
+    for _ in range(max(1, a.replays)):
+        wall, ms_launch = runner.timed(barrier)
+        if dist is not None:
+            t = torch.tensor([wall, ms_launch], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall, ms_launch = float(t[0]), float(t[1])
+        replays.append((wall, ms_launch))
+    order = sorted(range(len(replays)), key=lambda i: replays[i][0])
+    wall, ms_launch = replays[order[len(order) // 2]]  # the median replay: exactly K steps
     total_blocks = n * world * a.steps
     value = total_blocks / wall
-    achieved = runner.bytes_per_block * n / (ms_launch * 1e-3) / 1e9
+    bytes_launch = runner.bytes_per_block * n
+    achieved = bytes_launch / (ms_launch * 1e-3) / 1e9
+    achieved_wall = bytes_launch * a.steps / wall / 1e9
 
     traffic = None
     tp = ROOT / "profiles" / "traffic.json"
     if tp.exists():
         try:
-            tj = json.loads(tp.read_text())
-            traffic = tj.get("%s_%s" % (a.workload, a.layout))
+            traffic = json.loads(tp.read_text()).get("%s_%s" % (a.workload, a.layout))
         except Exception:
             traffic = None
 
@@ -246,24 +311,38 @@ def main():
         "config": {"workload": wl, "blocks_per_gpu": n, "layout": a.layout, "sharding": "blocks by rank, no collective",
                    "launch": "hipGraph of %d launches" % a.steps if graphed else "host launches",
                    "output_ring_sets": runner.nsets},
+        "timing": {"replays": len(replays), "reported": "median replay (exactly %d steps)" % a.steps,
+                   "ms_per_step_wall": [w * 1e3 / a.steps for w, _ in replays],
+                   "ms_per_step_events": [m for _, m in replays],
+                   "min_ms_per_step": min(w for w, _ in replays) * 1e3 / a.steps,
+                   "max_ms_per_step": max(w for w, _ in replays) * 1e3 / a.steps,
+                   "timed_seconds_total": sum(w for w, _ in replays)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "frac_events": achieved / HBM_PEAK_GBPS,
+                     "frac_wall": achieved_wall / HBM_PEAK_GBPS,
+                     "frac_events_min": bytes_launch / (max(m for _, m in replays) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "frac_events_max": bytes_launch / (min(m for _, m in replays) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": traffic,
                      "kernel": "aesw::encrypt_kernel", "launch_ms": ms_launch,
                      "algorithmic_bytes_per_block": runner.bytes_per_block,
-                     "algorithmic_bytes_per_launch": runner.bytes_per_block * n,
-                     "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE, profiles/traffic.json)"},
+                     "algorithmic_bytes_per_launch": bytes_launch,
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE)",
+                     "traffic_source": "committed PMC passes of this command (profiles/traffic.json), not collected in this run"},
         "achieved_hbm_GBps_all_gpus": achieved * world,
     }
 
     extras = {}
     if rank == 0 and dist is None and not a.no_extras:
-        # secondary measurements (not `value`): the other layout and BASELINE configs[2]
+        import numpy as np
         del runner
         torch.cuda.empty_cache()
+        # every host-path extra schedules its own key (the headline runner has per-block keys: nothing scheduled yet)
+        hkey = torch.from_numpy(np.random.default_rng(SEED + 5).integers(0, 256, 16, dtype=np.uint8)).cuda()
+        ctx.schedule_key(hkey, layout=pkg.LAYOUT_PACKED, key_slab=False)
+        torch.cuda.synchronize()
         try:  # PCIe-inclusive rate of the host-pointer entry point (never `value`).  Runs before the large
             # runners below: for a few hundred ms after gigabytes of device memory are freed, device-to-host
             # copies run at ~36 GB/s instead of ~55 GB/s (tools/pinned_probe.py).
-            import numpy as np
             time.sleep(0.3)
             nn = 1 << 20
             if host_bufs is None:
@@ -285,25 +364,6 @@ def main():
                 dt = sorted(dts)[1]  # median of three calls
                 res[kind] = {"blocks_per_s": nn / dt, "GBps_to_host": nn * 3024 / dt / 1e9}
                 del outs
-            # streaming form: a consumer callback per 2^15-block chunk while the next chunk is in flight
-            seen = [0]
-
-            def consume(first, count, x, y, z):
-                seen[0] += count
-                return 0
-
-            ctx.encrypt_witness_stream(hpt, None, consume, layout=pkg.LAYOUT_PACKED)
-            dts = []
-            for _ in range(3):
-                seen[0] = 0
-                t0 = time.perf_counter()
-                ctx.encrypt_witness_stream(hpt, None, consume, layout=pkg.LAYOUT_PACKED)
-                dts.append(time.perf_counter() - t0)
-            dt = sorted(dts)[1]
-            res["stream"] = {"blocks": nn, "blocks_per_s": nn / dt, "GBps_to_host": nn * 3024 / dt / 1e9,
-                             "chunks_seen_blocks": seen[0]}
-            # the closure-computed cells only (AESW_LAYOUT_VALUES, 1 056 B per block): what a host that keeps
-            # the chips' copy_advice() calls has to receive
             vouts = [np.empty(0, np.uint8), pinned_outs[1][:nn * 448], pinned_outs[2][:nn * 608]]
             ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_VALUES, out_cols=vouts)
             dts = []
@@ -316,7 +376,7 @@ def main():
             pkg.api.host_free(hpt)
             for o in pinned_outs:
                 pkg.api.host_free(o)
-            del pinned_outs, hpt
+            del pinned_outs, hpt, vouts
             # the link itself: one page-locked 1 GiB device-to-host copy, for scale
             dsrc = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
             hdst = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
@@ -331,16 +391,88 @@ def main():
             extras["pcie_inclusive"] = res
         except Exception as e:
             extras["pcie_inclusive"] = {"error": str(e)}
-        for name, nn, pbk, lay in (("c1_dense", 1 << 16, False, pkg.LAYOUT_DENSE),
-                                   ("c1_packed_2p20", 1 << 20, False, pkg.LAYOUT_PACKED),
-                                   ("c2_packed", 1 << 20, True, pkg.LAYOUT_PACKED),
-                                   ("c2_dense", 1 << 20, True, pkg.LAYOUT_DENSE),
-                                   ("c1_values", 1 << 16, False, pkg.LAYOUT_VALUES),
-                                   ("c1_values_2p20", 1 << 20, False, pkg.LAYOUT_VALUES)):
+        try:  # BASELINE configs[4] on one GPU: 2^24 blocks streamed to a verifying consumer, the parts timed separately
+            import oracle_lib
+            orc = oracle_lib.Oracle()
+            n4 = 1 << a.c4_log2_blocks
+            pt4 = np.random.default_rng(SEED + 4).integers(0, 256, (n4, 16), dtype=np.uint8)
+            key4 = hkey.cpu().numpy()
+            c4 = {"blocks": n4, "note": "aesw_encrypt_witness_stream, scheduled key: chunk i+1's kernel and D2H overlap the consumer of chunk i; "
+                                        "kernel_s / d2h_s are device time summed over chunks (HIP events), consumer_s / wait_s host time; "
+                                        "the consumer checks pt ^ rk0 on every chunk and compares 6 sampled chunks x 256 blocks with the oracle"}
+            for name, lay, olay in (("values", pkg.LAYOUT_VALUES, oracle_lib.VALUES), ("packed", pkg.LAYOUT_PACKED, oracle_lib.PACKED)):
+                strides = [pkg.column_stride(lay, c) for c in range(3)]
+                chunk = ctx.get_option("chunk_blocks")
+                sampled = set(int(v) for v in np.linspace(0, -(-n4 // chunk) - 1, 6).astype(int))
+                bad = [0]
+
+                def consume(first, count, x, y, z):
+                    p = pt4[first:first + count]
+                    if not np.array_equal(z.reshape(count, strides[2])[:, :16], p ^ key4):
+                        bad[0] += 1
+                    if first // chunk in sampled:
+                        m = min(count, 256)
+                        e = orc.encrypt_witness(p[:m], key4, layout=olay)
+                        for got, exp, s in ((x, e.x, strides[0]), (y, e.y, strides[1]), (z, e.z, strides[2])):
+                            if s and not np.array_equal(got[:m * s], exp):
+                                bad[0] += 1
+                    return 0
+
+                ctx.encrypt_witness_stream(pt4[:1 << 16], None, lambda *args: 0, layout=lay)  # sizes the context's buffers
+                t0 = time.perf_counter()
+                ctx.encrypt_witness_stream(pt4, None, consume, layout=lay)
+                dt = time.perf_counter() - t0
+                st = ctx.last_stream_stats()
+                per = sum(strides)
+                c4[name] = {"blocks_per_s": n4 / dt, "seconds": dt, "GBps_to_host": n4 * per / dt / 1e9,
+                            "kernel_s": st["kernel_ns"] * 1e-9, "kernel_blocks_per_s": n4 / (st["kernel_ns"] * 1e-9),
+                            "d2h_s": st["d2h_ns"] * 1e-9, "d2h_GBps": st["bytes_to_host"] / (st["d2h_ns"] * 1e-9) / 1e9,
+                            "consumer_s": st["consumer_ns"] * 1e-9, "wait_s": st["wait_ns"] * 1e-9, "chunks": st["chunks"],
+                            "mismatches": bad[0]}
+            del pt4
+            extras["c4"] = c4
+        except Exception as e:
+            extras["c4"] = {"error": str(e)}
+        try:  # whole Fr advice columns of a K=20, N=5 circuit delivered to the host, column by column
+            k, n_sets = 20, 5
+            nn = pkg.block_capacity(k, n_sets)
+            apt = torch.randint(0, 256, (nn, 16), dtype=torch.uint8, device="cuda")
+            kw = ctx.schedule_key(hkey, layout=pkg.LAYOUT_PACKED, key_slab=True)
+            wit = ctx.encrypt_witness(apt, None, layout=pkg.LAYOUT_PACKED)
+            torch.cuda.synchronize()
+            sink = np.empty((1 << k, 32), np.uint8)  # the host's advice polynomial buffer: one bulk copy per column
+
+            def take(col, cells):
+                np.copyto(sink, cells)
+                return 0
+
+            ctx.assemble_advice_stream(k, n_sets, wit, kw, nn, lambda col, cells: 0, layout=pkg.LAYOUT_PACKED, as_fr=True)
+            t0 = time.perf_counter()
+            ctx.assemble_advice_stream(k, n_sets, wit, kw, nn, take, layout=pkg.LAYOUT_PACKED, as_fr=True)
+            dt = time.perf_counter() - t0
+            st = ctx.last_stream_stats()
+            extras["fr_columns_to_host"] = {
+                "circuit": "K=20, N=5: 16 advice columns x 2^20 Fr cells (512 MiB), %d blocks" % nn,
+                "seconds": dt, "blocks_per_s": nn / dt, "GBps_to_host": st["bytes_to_host"] / dt / 1e9,
+                "kernel_s": st["kernel_ns"] * 1e-9, "d2h_s": st["d2h_ns"] * 1e-9, "consumer_s": st["consumer_ns"] * 1e-9,
+                "wait_s": st["wait_ns"] * 1e-9,
+                "note": "aesw_assemble_advice_stream: assemble column j+1 and copy it while the host bulk-copies column j "
+                        "(one 32 MiB memcpy per column instead of 2^20 assign_advice calls); compare host_synthesize"}
+            del apt, wit, sink
+        except Exception as e:
+            extras["fr_columns_to_host"] = {"error": str(e)}
+        for name, nn, xpbk, lay in (("c1_packed", 1 << 16, False, pkg.LAYOUT_PACKED),
+                                    ("c1_packed_2p20", 1 << 20, False, pkg.LAYOUT_PACKED),
+                                    ("c1_values", 1 << 16, False, pkg.LAYOUT_VALUES),
+                                    ("c1_values_2p20", 1 << 20, False, pkg.LAYOUT_VALUES),
+                                    ("c1_dense", 1 << 16, False, pkg.LAYOUT_DENSE),
+                                    ("c2_dense", 1 << 20, True, pkg.LAYOUT_DENSE)):
             try:
-                r = Runner(pkg, ctx, torch, nn, pbk, lay, pbk, SEED + 7)
+                r = Runner(pkg, ctx, torch, nn, xpbk, lay, xpbk, SEED + 7)
                 steps = 50 if nn <= (1 << 16) else 12
-                w, ms, _ = r.run(steps, 3, not a.no_graph)
+                r.prepare(steps, 3, not a.no_graph)
+                runs = sorted((r.timed() for _ in range(3)), key=lambda t: t[1])
+                w, ms = runs[1]
                 extras[name] = {"blocks": nn, "blocks_per_s": nn * steps / w, "launch_ms": ms,
                                 "achieved_GBps": r.bytes_per_block * nn / (ms * 1e-3) / 1e9,
                                 "frac": r.bytes_per_block * nn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -350,35 +482,27 @@ def main():
             except Exception as e:  # keep the headline even if an extra fails
                 extras[name] = {"error": str(e)}
         try:  # where the end-to-end time goes: the host's synthesize() assigning the device witness cell by cell
-            import numpy as np
             k, n_sets = 20, 3
             nn = pkg.block_capacity(k, n_sets)
             hpt = np.random.default_rng(SEED + 3).integers(0, 256, (nn, 16), dtype=np.uint8)
-            hkey = np.random.default_rng(SEED + 4).integers(0, 256, 16, dtype=np.uint8)
+            hk = np.random.default_rng(SEED + 4).integers(0, 256, 16, dtype=np.uint8)
+            res = {}
+            for label, kw in (("blocks_per_s", {}), ("bulk_assign_blocks_per_s", {"bulk_assign": True}),
+                              ("streaming_values_only_blocks_per_s", {"streaming": True})):
+                t0 = time.perf_counter()
+                hc = pkg.HostCircuit.aes(ctx, k, n_sets, hk, hpt, **kw)
+                res[label] = nn / (time.perf_counter() - t0)
+                if not kw:
+                    res["regions_per_s"] = hc.num_regions * res[label] / nn
+                hc.close()
             t0 = time.perf_counter()
-            hc = pkg.HostCircuit.aes(ctx, k, n_sets, hkey, hpt)
-            dt = time.perf_counter() - t0
-            regions = hc.num_regions
+            hc = pkg.HostCircuit.aes_columns(ctx, k, n_sets, hk, hpt)
+            res["whole_columns_blocks_per_s"] = nn / (time.perf_counter() - t0)
             hc.close()
-            t0 = time.perf_counter()
-            hc = pkg.HostCircuit.aes(ctx, k, n_sets, hkey, hpt, bulk_assign=True)
-            dtb = time.perf_counter() - t0
-            hc.close()
-            t0 = time.perf_counter()
-            hc = pkg.HostCircuit.aes(ctx, k, n_sets, hkey, hpt, streaming=True)
-            dts = time.perf_counter() - t0
-            hc.close()
-            t0 = time.perf_counter()
-            hc = pkg.HostCircuit.aes_columns(ctx, k, n_sets, hkey, hpt)
-            dtc = time.perf_counter() - t0
-            hc.close()
-            extras["host_synthesize"] = {"circuit": "FixedAes128Config<20,3>, %d blocks (full)" % nn, "seconds": dt,
-                                         "whole_columns_blocks_per_s": nn / dtc,
-                                         "streaming_values_only_blocks_per_s": nn / dts,
-                                         "blocks_per_s": nn / dt, "regions_per_s": regions / dt,
-                                         "bulk_assign_blocks_per_s": nn / dtb,
-                                         "note": "C++ host mirror: table + schedule_key + encrypt() per block, one thread, "
-                                                 "device witness generation included (negligible)"}
+            res["circuit"] = "FixedAes128Config<20,3>, %d blocks (full)" % nn
+            res["note"] = ("C++ host mirror (libaesw_host.so): table + schedule_key + encrypt() per block, one thread, packed device "
+                           "witness generation included (negligible)")
+            extras["host_synthesize"] = res
         except Exception as e:
             extras["host_synthesize"] = {"error": str(e)}
         try:  # byte cells -> 32-byte Fr cells
@@ -414,48 +538,15 @@ def main():
             del dkeys, kwit
         except Exception as e:
             extras["key_schedule"] = {"error": str(e)}
-        try:  # the whole advice matrix of a K=20, N=5 circuit as Fr cells (bulk assignment)
-            k, n_sets = 20, 5
-            nn = pkg.block_capacity(k, n_sets)
-            apt = torch.randint(0, 256, (nn, 16), dtype=torch.uint8, device="cuda")
-            akey = torch.randint(0, 256, (16,), dtype=torch.uint8, device="cuda")
-            kw = ctx.schedule_key(akey, layout=pkg.LAYOUT_PACKED, key_slab=True)
-            wit = ctx.encrypt_witness(apt, None, layout=pkg.LAYOUT_PACKED)
-            adv = ctx.assemble_advice(k, n_sets, wit, kw, nn, layout=pkg.LAYOUT_PACKED, as_fr=True)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                del adv
-                adv = ctx.assemble_advice(k, n_sets, wit, kw, nn, layout=pkg.LAYOUT_PACKED, as_fr=True)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 5
-            extras["assemble_fr"] = {"circuit": "K=20, N=5: 16 advice columns x 2^20 Fr cells, %d blocks" % nn,
-                                     "launch_ms": ms, "written_GBps": adv.numel() / (ms * 1e-3) / 1e9}
-            del adv, wit, apt
-        except Exception as e:
-            extras["assemble_fr"] = {"error": str(e)}
         line["extra"] = extras
     if rank == 0 and dist is None and not a.no_cpu:
-        line["cpu_baseline"] = cpu_baseline()
+        line["cpu_baseline"] = cpu_baseline(pbk)
     elif rank == 0:
         line["cpu_baseline"] = None
     if dist is not None:
-        # optional exchange step, timed separately (never part of `value`): gather every rank's columns on
-        # rank 0.  A watchdog emits the headline line anyway if the exchange stalls.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                line.setdefault("gather", {"error": "timed out"})
-                line.setdefault("c3", {"error": "timed out"})
-                print(json.dumps(line), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(150.0, give_up)
-        dog.daemon = True
-        dog.start()
+        # optional exchange step, timed separately (never part of `value`): gather every rank's columns on rank 0
+        # through the C ABI's RCCL gather.  A per-phase watchdog reports a stalled exchange and exits NON-ZERO.
+        dog = Watchdog(rank, line)
         strides = [pkg.column_stride(layout, c) for c in range(3)]
 
         def timed_gather(wset, nblk):
@@ -463,7 +554,7 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            full = pkg.sharding.gather_columns(gcols, [nblk] * world, strides, dst=0)
+            full = pkg.sharding.gather_columns(gcols, [nblk] * world, strides, dst=0, ctx=ctx if a.backend == "nccl" else None)
             torch.cuda.synchronize()
             dist.barrier()
             dt = time.perf_counter() - t0
@@ -471,12 +562,16 @@ def main():
             return dt
 
         try:
-            timed_gather(runner.sets[0], n)  # untimed: connection set-up of the peer-to-peer channels
+            dog.arm("gather warm-up (RCCL communicator + peer channel set-up)", 120.0)
+            timed_gather(runner.sets[0], n)
+            dog.arm("gather", 60.0)
             dt = timed_gather(runner.sets[0], n)
+            dog.disarm()
             if rank == 0:
                 line["gather"] = {"seconds": dt, "GBps_into_root": (world - 1) * n * sum(strides) / dt / 1e9,
-                                  "note": "send/recv of per-rank column ranges to rank 0 (RCCL over xGMI with nccl), outside `value`"}
+                                  "note": "aesw_gather_columns_device: RCCL send/recv of per-rank column ranges to rank 0 over xGMI, outside `value`"}
         except Exception as e:
+            dog.disarm()
             if rank == 0:
                 line["gather"] = {"error": str(e)}
         if not a.no_extras:
@@ -485,12 +580,15 @@ def main():
                 del runner
                 torch.cuda.empty_cache()
                 n3 = 1 << (a.c3_log2_blocks or 21)
+                dog.arm("c3 generation", 120.0)
                 r3 = Runner(pkg, ctx, torch, n3, False, layout, False, SEED + 11 + rank)
                 steps3 = 10
                 w3, ms3, _ = r3.run(steps3, 2, not a.no_graph, barrier)
                 t3 = torch.tensor([w3, ms3], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
                 dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+                dog.arm("c3 gather", 120.0)
                 dt3 = timed_gather(r3.sets[0], n3)
+                dog.disarm()
                 if rank == 0:
                     line["c3"] = {"workload": "2^%d blocks per GPU x %d GPUs, one shared key, %s columns" % (a.c3_log2_blocks or 21, world, a.layout),
                                   "blocks_total": n3 * world, "blocks_per_s": n3 * world * steps3 / float(t3[0]),
@@ -500,14 +598,16 @@ def main():
                                   "note": "generation and gather timed separately; the gather is bound by the root's xGMI ingest"}
                 del r3
             except Exception as e:
+                dog.disarm()
                 if rank == 0:
                     line["c3"] = {"error": str(e)}
-        dog.cancel()
+        dog.arm("shutdown", 60.0)
         try:
             dist.barrier()
             dist.destroy_process_group()
         except Exception:
             pass
+        dog.disarm()
     if rank == 0:
         print(json.dumps(line))
 

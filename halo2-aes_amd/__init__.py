@@ -17,14 +17,14 @@ Layout:
 from . import constants
 from .constants import (AES_ROWS, KEY_ROWS, KEY_SCHEDULE_ROWS, LAYOUT_DENSE, LAYOUT_PACKED, LAYOUT_VALUES, TABLE_ROWS, WORDS_ROWS,
                         fips_tables, reference_tables)
-from .api import (AeswError, Context, HostCircuit, assemble_selectors, KeyWitness, Witness, block_capacity, block_copy_graph, block_placement,
+from .api import (AeswError, Comm, Context, HostCircuit, assemble_selectors, KeyWitness, Witness, block_capacity, block_copy_graph, block_placement,
                   column_stride, key_copy_graph,
                   device_count, key_column_stride, key_packed_index, layout_index, load_library, packed_index, selector_tags)
 from . import sharding
 
 __all__ = [
     "constants", "AES_ROWS", "KEY_ROWS", "KEY_SCHEDULE_ROWS", "LAYOUT_DENSE", "LAYOUT_PACKED", "LAYOUT_VALUES", "TABLE_ROWS",
-    "WORDS_ROWS", "fips_tables", "reference_tables", "AeswError", "Context", "HostCircuit", "assemble_selectors", "KeyWitness", "Witness",
+    "WORDS_ROWS", "fips_tables", "reference_tables", "AeswError", "Comm", "Context", "HostCircuit", "assemble_selectors", "KeyWitness", "Witness",
     "block_capacity", "block_copy_graph", "block_placement", "column_stride", "key_copy_graph", "device_count", "key_column_stride", "key_packed_index",
     "layout_index", "load_library", "packed_index", "selector_tags", "sharding",
 ]

@@ -36,6 +36,13 @@ class AeswError(RuntimeError):
         super().__init__(msg)
 
 
+class StreamStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("chunks", "bytes_to_host", "kernel_ns", "d2h_ns", "consumer_ns", "wait_ns", "wall_ns")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class KeySlab(C.Structure):
     _fields_ = [("w", C.c_void_p), ("kx", C.c_void_p), ("ky", C.c_void_p), ("kz", C.c_void_p)]
 
@@ -72,6 +79,8 @@ SYMBOLS = {
     "aesw_key_schedule_witness": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P]),
     "aesw_encrypt_witness_stream": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P]),
     "aesw_lookup_table": (_I, [_P, _P, _P, _P, _P]),
+    "aesw_last_stream_stats": (_I, [_P, _P]),
+    "aesw_assemble_advice_stream": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
     "aesw_host_alloc": (_P, [C.c_size_t]),
     "aesw_host_free": (None, [_P]),
     "aesw_comm_unique_id": (_I, [_P]),
@@ -554,6 +563,37 @@ class Context:
             raise err[0]
         self._check(rc, "aesw_encrypt_witness_stream")
 
+    def last_stream_stats(self) -> dict:
+        """Where the time of the last streaming call went (aesw_last_stream_stats)."""
+        st = StreamStats()
+        self._check(self._lib.aesw_last_stream_stats(self._h, C.byref(st)), "aesw_last_stream_stats")
+        return st.as_dict()
+
+    def assemble_advice_stream(self, k: int, n_sets: int, witness: "Witness", key_witness, n_blocks: int, consume,
+                               layout: int = K.LAYOUT_PACKED, as_fr: bool = True):
+        """aesw_assemble_advice_stream: consume(column, cells) per advice column with a numpy view of the page-locked
+        buffer (2^k bytes, or [2^k, 32] Fr cells), valid only during the call, while the next column is in flight."""
+        self._torch().cuda.current_stream(self.device).synchronize()  # the slabs must be complete
+        err = []
+
+        @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint8), C.c_uint64)
+        def cb(_user, col, cells, n_cells):
+            try:
+                a = np.ctypeslib.as_array(cells, shape=(n_cells * (32 if as_fr else 1),))
+                r = consume(int(col), a.reshape(n_cells, 32) if as_fr else a)
+                return int(r or 0)
+            except Exception as e:  # never let an exception cross the C boundary
+                err.append(e)
+                return 1
+
+        ks = KeySlab(*[t.data_ptr() for t in key_witness[:4]]) if key_witness is not None else None
+        rc = self._lib.aesw_assemble_advice_stream(
+            self._h, k, n_sets, n_blocks, layout, witness.x.data_ptr(), witness.y.data_ptr(), witness.z.data_ptr(),
+            C.byref(ks) if ks is not None else None, 1 if as_fr else 0, C.cast(cb, C.c_void_p), None)
+        if err:
+            raise err[0]
+        self._check(rc, "aesw_assemble_advice_stream")
+
     def key_schedule_witness_host(self, keys: np.ndarray, layout: int = K.LAYOUT_PACKED) -> KeyWitness:
         keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 16)
         n = keys.shape[0]
@@ -570,6 +610,61 @@ class Context:
         rc = self._lib.aesw_lookup_table(self._h, *[_np_ptr(t[i]) for i in range(4)])
         self._check(rc, "aesw_lookup_table")
         return t
+
+
+class Comm:
+    """aesw_comm: the RCCL communicator of the C ABI (one process per GPU).  `unique_id()` on one rank, carried to
+    the others by the host's own means, then Comm(ctx, nranks, rank, id) on every rank (collective)."""
+
+    def __init__(self, ctx: "Context", nranks: int, rank: int, uid: bytes | None = None):
+        self._lib = ctx._lib
+        self._h = C.c_void_p()
+        self.nranks, self.rank, self.ctx = nranks, rank, ctx
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid) if uid is not None else None
+        rc = self._lib.aesw_comm_create(ctx._h, nranks, rank, buf, C.byref(self._h))
+        if rc:
+            raise AeswError(rc, self._lib.aesw_comm_last_error().decode())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.aesw_comm_unique_id(buf)
+        if rc:
+            raise AeswError(rc, lib.aesw_comm_last_error().decode())
+        return bytes(buf)
+
+    def close(self):
+        if self._h:
+            self._lib.aesw_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def set_max_message(self, nbytes: int):
+        rc = self._lib.aesw_comm_set_max_message(self._h, nbytes)
+        if rc:
+            raise AeswError(rc)
+
+    def gather_columns(self, columns, counts, strides, root: int = 0, out=None):
+        """aesw_gather_columns_device on torch's current stream.  columns: this rank's flat uint8 device tensors;
+        returns the gathered tensors on `root` (allocated unless `out` is given), None elsewhere."""
+        import torch
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        strides_a = np.ascontiguousarray(strides, dtype=np.uint32)
+        if counts.size != self.nranks or len(columns) != strides_a.size:
+            raise ValueError("counts/strides do not match ranks / columns")
+        total = int(counts.sum())
+        n = len(columns)
+        send = (C.c_void_p * n)(*[c.data_ptr() if c.numel() else None for c in columns])
+        recv = None
+        if self.rank == root:
+            if out is None:
+                out = [torch.empty(total * int(s), dtype=torch.uint8, device=c.device) for c, s in zip(columns, strides_a)]
+            recv = (C.c_void_p * n)(*[o.data_ptr() if o.numel() else None for o in out])
+        stream = C.c_void_p(torch.cuda.current_stream(self.ctx.device).cuda_stream)
+        rc = self._lib.aesw_gather_columns_device(self._h, root, n, send, recv, _np_ptr(counts), _np_ptr(strides_a), stream)
+        if rc:
+            raise AeswError(rc, self._lib.aesw_comm_last_error().decode())
+        return out if self.rank == root else None
 
 
 class HostCircuit:

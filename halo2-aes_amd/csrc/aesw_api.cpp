@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct aesw_ctx {
     size_t bounce_bytes = 0;
     uint8_t *scratch = nullptr;  // device buffers of the host-pointer path (grow-only)
     size_t scratch_bytes = 0;
+    aesw_stream_stats stats = {};  // of the last streaming call
 };
 
 namespace {
@@ -202,6 +204,7 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
         if (rc == AESW_OK) T(hipMemcpy(ctx->d_ftab[l], ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(flush table)");
     }
     T(hipEventCreateWithFlags(&ctx->key_ready, hipEventDisableTiming), "hipEventCreate(key_ready)");
+    if (rc == AESW_OK) T(warm_launch_attributes(), "hipFuncSetAttribute(max dynamic LDS)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_pidx, pidx.data(), pidx.size() * sizeof(int16_t), hipMemcpyHostToDevice), "hipMemcpy(pidx)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_fr_lut, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy(fr_lut)");
@@ -523,28 +526,46 @@ int aesw_lookup_table_device(aesw_ctx *ctx, uint8_t *d_t0, uint8_t *d_t1, uint8_
     return AESW_OK;
 }
 
-int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks, int layout, const uint8_t *d_x,
-                                const uint8_t *d_y, const uint8_t *d_z, const aesw_key_slab *ks, int as_fr, uint8_t *d_out,
-                                void *stream) {
+namespace {
+int fill_assemble_params(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks, int layout, const uint8_t *d_x, const uint8_t *d_y,
+                         const uint8_t *d_z, const aesw_key_slab *ks, AssembleParams *p) {
     if (!ctx || !valid_layout(layout) || layout == AESW_LAYOUT_VALUES /* whole columns need every cell */ || k < 2 || k > 32 ||
-        n_sets == 0 || n_sets > 1024 || !d_out || !aligned16(d_out))
+        n_sets == 0 || n_sets > 1024)
         return AESW_ERR_INVALID_ARG;
     if (n_blocks && (!d_x || !d_y || !d_z)) return AESW_ERR_INVALID_ARG;
     if (n_blocks > aesw_block_capacity(k, n_sets)) return AESW_ERR_CAPACITY;  // panic in the reference, src/aes128.rs:160-162
+    *p = AssembleParams{};
+    p->x = d_x; p->y = d_y; p->z = d_z;
+    if (ks) { p->kw = ks->w; p->kx = ks->kx; p->ky = ks->ky; p->kz = ks->kz; }
+    p->pidx = ctx->d_pidx;
+    p->fr_lut = ctx->d_fr_lut;
+    p->n_blocks = n_blocks;
+    p->k = k;
+    p->n_sets = n_sets;
+    p->col_first = 0;
+    p->col_count = 3 * n_sets + 1;
+    p->sx = aesw_column_stride(layout, 0); p->sy = aesw_column_stride(layout, 1); p->sz = aesw_column_stride(layout, 2);
+    p->kxs = aesw_key_column_stride(layout, 0); p->kys = aesw_key_column_stride(layout, 1); p->kzs = aesw_key_column_stride(layout, 2);
+    p->packed = layout == AESW_LAYOUT_PACKED;
+    return AESW_OK;
+}
+uint64_t now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+}  // namespace
+
+int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks, int layout, const uint8_t *d_x,
+                                const uint8_t *d_y, const uint8_t *d_z, const aesw_key_slab *ks, int as_fr, uint8_t *d_out,
+                                void *stream) {
+    if (!d_out || !aligned16(d_out)) return AESW_ERR_INVALID_ARG;
+    AssembleParams p;
+    const int rc = fill_assemble_params(ctx, k, n_sets, n_blocks, layout, d_x, d_y, d_z, ks, &p);
+    if (rc != AESW_OK) return rc;
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
-    AssembleParams p{};
-    p.x = d_x; p.y = d_y; p.z = d_z;
-    if (ks) { p.kw = ks->w; p.kx = ks->kx; p.ky = ks->ky; p.kz = ks->kz; }
-    p.pidx = ctx->d_pidx;
-    p.fr_lut = ctx->d_fr_lut;
     p.out = d_out;
-    p.n_blocks = n_blocks;
-    p.k = k;
-    p.n_sets = n_sets;
-    p.sx = aesw_column_stride(layout, 0); p.sy = aesw_column_stride(layout, 1); p.sz = aesw_column_stride(layout, 2);
-    p.kxs = aesw_key_column_stride(layout, 0); p.kys = aesw_key_column_stride(layout, 1); p.kzs = aesw_key_column_stride(layout, 2);
-    p.packed = layout == AESW_LAYOUT_PACKED;
     HIP_TRY(ctx, launch_assemble(p, as_fr != 0, ctx->fr_nt, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
@@ -792,23 +813,30 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
     } sync_guard{ctx};
     HIP_TRY(ctx, hipMemcpyAsync(d + o_pt, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
     if (keys) HIP_TRY(ctx, hipMemcpyAsync(d + o_keys, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
-    hipEvent_t done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    // per stage: kernel start / end, copy start / end (timed: aesw_last_stream_stats reports where the time went)
+    hipEvent_t started[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, copy0[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
     struct EvGuard {
-        hipEvent_t *a, *b;
-        ~EvGuard() { for (int i = 0; i < 2; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } }
-    } evg{done, copied};
+        hipEvent_t *e[4];
+        ~EvGuard() { for (auto *v : e) for (int i = 0; i < 2; ++i) if (v[i]) (void)hipEventDestroy(v[i]); }
+    } evg{{started, done, copy0, copied}};
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(ctx, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreate(&started[i]));
+        HIP_TRY(ctx, hipEventCreate(&done[i]));
+        HIP_TRY(ctx, hipEventCreate(&copy0[i]));
+        HIP_TRY(ctx, hipEventCreate(&copied[i]));
     }
+    aesw_stream_stats st = {};
+    const uint64_t t_begin = now_ns();
     uint64_t first[2] = {0, 0}, count[2] = {0, 0};
     bool busy[2] = {false, false};
     auto issue = [&](int s, uint64_t b0, uint64_t m) -> int {
+        HIP_TRY(ctx, hipEventRecord(started[s], ctx->s_compute));
         int r = aesw_encrypt_witness_device(ctx, d + o_pt + 16 * b0, !keys ? nullptr : (pbk ? d + o_keys + 16 * b0 : d + o_keys), per_block_keys, m,
                                             layout, d + col_off[s][0], d + col_off[s][1], d + col_off[s][2], nullptr, nullptr, ctx->s_compute);
         if (r != AESW_OK) return r;
         HIP_TRY(ctx, hipEventRecord(done[s], ctx->s_compute));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
+        HIP_TRY(ctx, hipEventRecord(copy0[s], ctx->s_copy));
         for (int c = 0; c < 3; ++c)
             if (strides[c])
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[s] + boff[c], d + col_off[s][c], m * strides[c], hipMemcpyDeviceToHost, ctx->s_copy));
@@ -827,11 +855,21 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
     }
     for (int s = 0;; s ^= 1) {
         if (!busy[s]) break;
+        const uint64_t t0 = now_ns();
         HIP_TRY(ctx, hipEventSynchronize(copied[s]));
+        const uint64_t t1 = now_ns();
         busy[s] = false;
-        if (consume(user, first[s], count[s], strides[0] ? ctx->bounce[s] + boff[0] : nullptr /* AESW_LAYOUT_VALUES: no x */,
-                    ctx->bounce[s] + boff[1], ctx->bounce[s] + boff[2]) != 0)
-            return AESW_ERR_MISMATCH;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, started[s], done[s]) == hipSuccess) st.kernel_ns += (uint64_t)(ms * 1e6);
+        if (hipEventElapsedTime(&ms, copy0[s], copied[s]) == hipSuccess) st.d2h_ns += (uint64_t)(ms * 1e6);
+        const int cr = consume(user, first[s], count[s], strides[0] ? ctx->bounce[s] + boff[0] : nullptr /* AESW_LAYOUT_VALUES: no x */,
+                               ctx->bounce[s] + boff[1], ctx->bounce[s] + boff[2]);
+        const uint64_t t2 = now_ns();
+        st.wait_ns += t1 - t0;
+        st.consumer_ns += t2 - t1;
+        st.chunks += 1;
+        st.bytes_to_host += count[s] * (strides[0] + strides[1] + strides[2]);
+        if (cr != 0) { st.wall_ns = now_ns() - t_begin; ctx->stats = st; return AESW_ERR_MISMATCH; }
         if (b0 < n) {
             const uint64_t m = n - b0 < chunk ? n - b0 : chunk;
             rc = issue(s, b0, m);
@@ -839,6 +877,95 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
             b0 += m;
         }
     }
+    st.wall_ns = now_ns() - t_begin;
+    ctx->stats = st;
+    return AESW_OK;
+}
+
+int aesw_last_stream_stats(const aesw_ctx *ctx, aesw_stream_stats *out) {
+    if (!ctx || !out) return AESW_ERR_INVALID_ARG;
+    *out = ctx->stats;
+    return AESW_OK;
+}
+
+// Whole advice columns of a K/N circuit to the host, column by column ("the host can bulk-copy into
+// halo2's advice polynomials"): column j is assembled on s_compute into one of two device buffers, travels D2H on
+// s_copy into one of two page-locked buffers, and is handed to `consume` while column j+1 is assembled and copied.
+int aesw_assemble_advice_stream(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks, int layout, const uint8_t *d_x,
+                                const uint8_t *d_y, const uint8_t *d_z, const aesw_key_slab *ks, int as_fr, aesw_column_fn consume,
+                                void *user) {
+    if (!consume) return AESW_ERR_INVALID_ARG;
+    AssembleParams p;
+    int rc = fill_assemble_params(ctx, k, n_sets, n_blocks, layout, d_x, d_y, d_z, ks, &p);
+    if (rc != AESW_OK) return rc;
+    if (k > 28) return AESW_ERR_INVALID_ARG;  // one column must fit the staging buffers
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    rc = ensure_streams(ctx);
+    if (rc != AESW_OK) return rc;
+    const uint64_t rows = (uint64_t)1 << k;
+    const size_t col_bytes = (size_t)rows * (as_fr ? AESW_FR_BYTES : 1);
+    const size_t slot = (col_bytes + 255) / 256 * 256;
+    rc = ensure_scratch(ctx, 2 * slot);
+    if (rc != AESW_OK) return rc;
+    rc = ensure_bounce(ctx, slot);
+    if (rc != AESW_OK) return rc;
+    struct SyncGuard {
+        aesw_ctx *c;
+        ~SyncGuard() { (void)hipStreamSynchronize(c->s_copy); (void)hipStreamSynchronize(c->s_compute); }
+    } sync_guard{ctx};
+    hipEvent_t ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // per stage: kernel start/end, copy start/end
+    struct EvGuard {
+        hipEvent_t (*e)[4];
+        ~EvGuard() { for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) if (e[i][j]) (void)hipEventDestroy(e[i][j]); }
+    } evg{ev};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) HIP_TRY(ctx, hipEventCreate(&ev[i][j]));
+    // the caller's slabs were produced on some stream of theirs: they must be complete before this call (documented)
+    const uint32_t ncols = 3 * n_sets + 1;
+    aesw_stream_stats st = {};
+    const uint64_t t_begin = now_ns();
+    auto issue = [&](int s, uint32_t col) -> int {
+        AssembleParams q = p;
+        q.col_first = col;
+        q.col_count = 1;
+        q.out = ctx->scratch + (size_t)s * slot;
+        HIP_TRY(ctx, hipEventRecord(ev[s][0], ctx->s_compute));
+        HIP_TRY(ctx, launch_assemble(q, as_fr != 0, ctx->fr_nt, ctx->s_compute));
+        HIP_TRY(ctx, hipEventRecord(ev[s][1], ctx->s_compute));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, ev[s][1], 0));
+        HIP_TRY(ctx, hipEventRecord(ev[s][2], ctx->s_copy));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->bounce[s], q.out, col_bytes, hipMemcpyDeviceToHost, ctx->s_copy));
+        HIP_TRY(ctx, hipEventRecord(ev[s][3], ctx->s_copy));
+        return AESW_OK;
+    };
+    uint32_t next = 0;
+    for (; next < 2 && next < ncols; ++next) {
+        rc = issue((int)next, next);
+        if (rc != AESW_OK) return rc;
+    }
+    for (uint32_t col = 0; col < ncols; ++col) {
+        const int s = (int)(col & 1);
+        const uint64_t t0 = now_ns();
+        HIP_TRY(ctx, hipEventSynchronize(ev[s][3]));
+        const uint64_t t1 = now_ns();
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev[s][0], ev[s][1]) == hipSuccess) st.kernel_ns += (uint64_t)(ms * 1e6);
+        if (hipEventElapsedTime(&ms, ev[s][2], ev[s][3]) == hipSuccess) st.d2h_ns += (uint64_t)(ms * 1e6);
+        const int r = consume(user, col, ctx->bounce[s], rows);
+        const uint64_t t2 = now_ns();
+        st.wait_ns += t1 - t0;
+        st.consumer_ns += t2 - t1;
+        st.chunks += 1;
+        st.bytes_to_host += col_bytes;
+        if (r != 0) { st.wall_ns = now_ns() - t_begin; ctx->stats = st; return AESW_ERR_MISMATCH; }
+        if (next < ncols) {
+            rc = issue(s, next++);
+            if (rc != AESW_OK) return rc;
+        }
+    }
+    st.wall_ns = now_ns() - t_begin;
+    ctx->stats = st;
     return AESW_OK;
 }
 

@@ -41,6 +41,8 @@ hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, 
 // flush-descriptor table of a layout (aesw_layout.h "scheduled flush"): size in 32-bit words, and the host-side builder
 int flush_table_words(int layout);
 void build_flush_tables(int layout, uint32_t *out);
+// hipFuncSetAttribute(max dynamic LDS) for every instantiation, once per device: called by aesw_create()
+hipError_t warm_launch_attributes();
 hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
 struct AssembleParams {
@@ -51,6 +53,7 @@ struct AssembleParams {
     uint8_t *out;
     uint64_t n_blocks;
     uint32_t k, n_sets;
+    uint32_t col_first, col_count;       // the advice columns to write (out holds col_count columns)
     uint32_t sx, sy, sz, kxs, kys, kzs;  // bytes per block / per key
     int packed;
 };

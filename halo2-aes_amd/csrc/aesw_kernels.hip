@@ -632,14 +632,14 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
         __syncthreads();
     }
     const uint64_t rows = (uint64_t)1 << a.k;
-    const uint64_t cells = (uint64_t)(3 * a.n_sets + 1) * rows;
+    const uint64_t cells = (uint64_t)a.col_count * rows;  // columns [col_first, col_first + col_count), out starts at col_first
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     if (AS_FR) {
         // one lane = one 16-byte half cell: a wave writes 1 KiB contiguously
         u32x4 *out = reinterpret_cast<u32x4 *>(a.out);
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells * 2; i += stride) {
             const uint64_t cell = i >> 1;
-            const uint32_t v = advice_cell(a, (uint32_t)(cell >> a.k), cell & (rows - 1));
+            const uint32_t v = advice_cell(a, a.col_first + (uint32_t)(cell >> a.k), cell & (rows - 1));
             gstore<NT>(&out[i], lut[v * 2 + (uint32_t)(i & 1)]);
         }
     } else {
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
         uint32_t *out = reinterpret_cast<uint32_t *>(a.out);
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells / 4; i += stride) {
             const uint64_t cell = i * 4;
-            const uint32_t col = (uint32_t)(cell >> a.k);
+            const uint32_t col = a.col_first + (uint32_t)(cell >> a.k);
             const uint64_t row = cell & (rows - 1);
             uint32_t v = 0;
 #pragma unroll
@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
 static hipError_t allow_large_lds(const void *fn, size_t lds) {
     if (lds <= 48 * 1024) return hipSuccess;
     struct Seen { const void *fn; int dev; size_t lds; };
-    static Seen seen[256];
+    static Seen seen[2048];
     static int n_seen = 0;
     static std::mutex mu;  // contexts on different host threads launch concurrently
     std::lock_guard<std::mutex> lock(mu);
@@ -674,7 +674,7 @@ static hipError_t allow_large_lds(const void *fn, size_t lds) {
     for (int i = 0; i < n_seen; ++i)
         if (seen[i].fn == fn && seen[i].dev == dev && seen[i].lds >= lds) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess && n_seen < 256) seen[n_seen++] = Seen{fn, dev, lds};
+    if (e == hipSuccess && n_seen < 2048) seen[n_seen++] = Seen{fn, dev, lds};
     return e;
 }
 
@@ -761,13 +761,56 @@ hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int nt
     return xt ? launch_key_nt<PACKED, true>(p, waves, nt, s) : launch_key_nt<PACKED, false>(p, waves, nt, s);
 }
 
+// Dynamic LDS above 48 KiB needs hipFuncSetAttribute once per (kernel, device).  aesw_create() does it here for every
+// instantiation a context can launch, so that no launch ever changes a function attribute later -- in particular not
+// while the caller's stream is being captured into a hipGraph (tests/test_gpu_graph_capture.py).
+template <int L, bool XT, int KM, bool KEMIT>
+static hipError_t warm_enc_nt() {
+    const size_t lds = TAB_BYTES + RKS_BYTES + 4 * (size_t)enc_wave_lds<L>(KEMIT);  // the largest group any option can ask for
+    const size_t cap = lds > 65536 ? 65536 : lds;
+    hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&encrypt_kernel<L, XT, KM, KEMIT, 0>), cap);
+    if (e == hipSuccess) e = allow_large_lds(reinterpret_cast<const void *>(&encrypt_kernel<L, XT, KM, KEMIT, 1>), cap);
+    if (e == hipSuccess) e = allow_large_lds(reinterpret_cast<const void *>(&encrypt_kernel<L, XT, KM, KEMIT, 2>), cap);
+    return e;
+}
+template <int L, bool XT>
+static hipError_t warm_layout() {
+    hipError_t e = warm_enc_nt<L, XT, KM_PRE, false>();
+    if (e == hipSuccess) e = warm_enc_nt<L, XT, KM_SHARED, false>();
+    if (e == hipSuccess) e = warm_enc_nt<L, XT, KM_PBK, false>();
+    if (e == hipSuccess) e = warm_enc_nt<L, XT, KM_PBK, true>();
+    return e;
+}
+template <int L, bool XT>
+static hipError_t warm_key() {
+    const size_t lds = TAB_BYTES + 4 * (size_t)(Stage<L>::KEY_BYTES + Stage<L>::RK_BYTES_W);
+    hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&key_kernel<L, XT, 0>), lds);
+    if (e == hipSuccess) e = allow_large_lds(reinterpret_cast<const void *>(&key_kernel<L, XT, 1>), lds);
+    if (e == hipSuccess) e = allow_large_lds(reinterpret_cast<const void *>(&key_kernel<L, XT, 2>), lds);
+    return e;
+}
+template <bool XT>
+static hipError_t warm_all() {
+    hipError_t e = warm_layout<DENSE, XT>();
+    if (e == hipSuccess) e = warm_layout<PACKED, XT>();
+    if (e == hipSuccess) e = warm_layout<VALUES, XT>();
+    if (e == hipSuccess) e = warm_key<DENSE, XT>();
+    if (e == hipSuccess) e = warm_key<PACKED, XT>();
+    return e;
+}
+hipError_t warm_launch_attributes() {
+    hipError_t e = warm_all<true>();  // both table paths: "force_table_path" can flip a context later
+    if (e == hipSuccess) e = warm_all<false>();
+    return e;
+}
+
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s) {
     hipLaunchKernelGGL(table_kernel, dim3((66561 + 255) / 256), dim3(256), 0, s, tables, t0, t1, t2, t3);
     return hipGetLastError();
 }
 
 hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int nt, hipStream_t s) {
-    const uint64_t cells = (uint64_t)(3 * p.n_sets + 1) << p.k;
+    const uint64_t cells = (uint64_t)p.col_count << p.k;
     uint64_t blocks = ((as_fr ? cells * 2 : cells / 4) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks == 0) blocks = 1;

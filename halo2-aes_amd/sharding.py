@@ -26,17 +26,44 @@ def shard_sizes(n: int, world: int) -> List[int]:
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
+_comms = {}  # (id of ctx, group) -> api.Comm
+
+
+def _aesw_comm(ctx, group):
+    """The C-ABI RCCL communicator of (ctx, group), created on first use: group rank 0 makes the unique id and the
+    existing process group carries it to the others."""
+    import torch
+    import torch.distributed as dist
+    from . import api
+
+    key = (id(ctx), id(group) if group is not None else None)
+    if key in _comms:
+        return _comms[key]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    uid = torch.zeros(128, dtype=torch.uint8, device="cuda:%d" % ctx.device)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(api.Comm.unique_id()), dtype=torch.uint8))
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(uid, src=src, group=group)
+    comm = api.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+    _comms[key] = comm
+    return comm
+
+
 def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[int], dst: int = 0, group=None,
-                   max_message_bytes: int = 1 << 30):
-    """Gather per-rank column slices on rank `dst`.
+                   max_message_bytes: int = 1 << 30, ctx=None):
+    """Gather per-rank column slices on group rank `dst`.
 
     columns: this rank's column tensors (uint8, flat, counts[rank]*stride bytes).
     counts:  blocks per rank (len == world).  strides: bytes per block per column.
     Returns the full columns on `dst` (list of tensors), None elsewhere.
-    Uses send/recv pairs so ragged shard sizes need no padding; with the nccl
-    backend every peer->root transfer rides its own xGMI link.  A rank's range of
-    one column travels as messages of at most `max_message_bytes` (BASELINE
-    configs[3] moves 2.9 GB per column and rank).
+
+    With the nccl backend and `ctx` (the rank's aesw Context) the exchange is the C ABI's
+    aesw_gather_columns_device -- RCCL send/recv inside one ncclGroupStart/End, enqueued on torch's current
+    stream, so it is ordered behind the kernels that produced the columns without a host synchronisation; a host
+    without torch calls the same entry point.  Otherwise (gloo in the CPU tests) it falls back to
+    torch.distributed point-to-point operations with the same index math.  A rank's range of one column travels
+    as messages of at most `max_message_bytes`.
     """
     import torch
     import torch.distributed as dist
@@ -47,11 +74,13 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
         raise ValueError("counts/strides do not match world size / columns")
     if max_message_bytes <= 0:
         raise ValueError("max_message_bytes must be positive")
+    if ctx is not None and dist.get_backend(group) == "nccl" and all(c.is_cuda for c in columns):
+        comm = _aesw_comm(ctx, group)
+        comm.set_max_message(max_message_bytes)
+        return comm.gather_columns([c[:counts[rank] * s] for c, s in zip(columns, strides)], counts, strides, root=dst)
     total = sum(counts)
     offs = [sum(counts[:r]) for r in range(world)]
-    # One grouped batch of point-to-point operations: with the nccl backend (RCCL) the group is
-    # issued as a single ncclGroupStart/End, so the root's receives from all peers proceed
-    # concurrently, each over its own xGMI link, instead of one peer after the other.
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)  # P2POp wants global ranks
     ops = []
     outs = None
     if rank == dst:
@@ -63,12 +92,12 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
                     view.copy_(col[:counts[r] * s])
                 elif counts[r]:
                     for o in range(0, view.numel(), max_message_bytes):
-                        ops.append(dist.P2POp(dist.irecv, view[o:o + max_message_bytes], r, group))
+                        ops.append(dist.P2POp(dist.irecv, view[o:o + max_message_bytes], peer(r), group))
     elif counts[rank]:
         for col, s in zip(columns, strides):
             mine = col[:counts[rank] * s].contiguous()
             for o in range(0, mine.numel(), max_message_bytes):
-                ops.append(dist.P2POp(dist.isend, mine[o:o + max_message_bytes], dst, group))
+                ops.append(dist.P2POp(dist.isend, mine[o:o + max_message_bytes], peer(dst), group))
     if ops:
         for q in dist.batch_isend_irecv(ops):
             q.wait()

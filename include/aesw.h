@@ -163,7 +163,13 @@ int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]);
  * and optionally emits its key-schedule witness (one key slab).  This is the
  * reference's call shape: schedule_key once, encrypt many times
  * (benches/aes128.rs:50-53).  The round keys are written on `stream`: later
- * encrypt calls must run on the same stream or after it has been synchronised. */
+ * an encrypt call on another stream is ordered behind them with an event (no host wait).  The
+ * context holds ONE scheduled key: scheduling another key while launches that use the previous one
+ * are still running on a different stream races; synchronise first.  Inside a hipGraph capture the
+ * scheduled-key encrypt must be captured on the stream the key was scheduled on.
+ * All launch attributes (dynamic LDS sizes) are set by aesw_create(): launches never change function
+ * attributes, so every *_device entry point may be captured into a hipGraph
+ * (hipStreamBeginCapture on `stream`) and replayed. */
 int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout,
                              const aesw_key_slab *d_key_slab, void *stream);
 /* d_keys: n*16 B when per_block_keys; 16 B (one key, expanded inside the call)
@@ -223,6 +229,33 @@ typedef int (*aesw_chunk_fn)(void *user, uint64_t first_block, uint64_t n_blocks
 int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys,
                                 int per_block_keys, uint64_t n, int layout, aesw_chunk_fn consume,
                                 void *user);
+/* Where the time of the last streaming call on this context went (aesw_encrypt_witness_stream,
+ * aesw_assemble_advice_stream): device time of the chunks' kernels and of their device-to-host
+ * copies (HIP events, summed over chunks; the two overlap each other and the consumer), host time
+ * spent inside `consume` and host time spent waiting for a chunk, and the call's wall time. */
+typedef struct aesw_stream_stats {
+    uint64_t chunks;
+    uint64_t bytes_to_host;
+    uint64_t kernel_ns;
+    uint64_t d2h_ns;
+    uint64_t consumer_ns;
+    uint64_t wait_ns;
+    uint64_t wall_ns;
+} aesw_stream_stats;
+int aesw_last_stream_stats(const aesw_ctx *ctx, aesw_stream_stats *out);
+/* The advice columns of a FixedAes128Config<K, n_sets> circuit delivered to the HOST, column by
+ * column (the host bulk-copies whole columns into halo2's advice polynomials
+ * instead of one assign_advice per cell, src/utils.rs:23, src/aes128.rs:187).  Inputs as for
+ * aesw_assemble_advice_device (device slabs, already complete: synchronise the stream that
+ * produced them first).  `consume` is called on the calling thread for columns 0 .. 3*n_sets in
+ * order with a page-locked buffer of 2^k cells (one byte each, or 32-byte little-endian
+ * Montgomery bn256::Fr cells when as_fr), valid only during the call, WHILE the next column is
+ * being assembled and copied.  A non-zero return aborts the stream (AESW_ERR_MISMATCH). */
+typedef int (*aesw_column_fn)(void *user, uint32_t column, const uint8_t *cells, uint64_t n_cells);
+int aesw_assemble_advice_stream(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks,
+                                int layout, const uint8_t *d_x, const uint8_t *d_y,
+                                const uint8_t *d_z, const aesw_key_slab *d_key_slab, int as_fr,
+                                aesw_column_fn consume, void *user);
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout,
                               uint8_t *w, uint8_t *kx, uint8_t *ky, uint8_t *kz, uint8_t *rk);
 /* host-pointer aesw_schedule_key_device: key is 16 host bytes, key_slab host buffers (optional) */

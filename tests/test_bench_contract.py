@@ -18,13 +18,30 @@ def test_defaults_and_constants(monkeypatch):
     b = _bench()
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = b.parse()
-    assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.workload == "c1" and a.layout == "packed"
+    # the headline is BASELINE configs[2]: 2^20 blocks, per-block keys + key-schedule witness, packed columns
+    assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.workload == "c2" and a.layout == "packed"
+    assert a.replays >= 5 and a.log2_blocks is None
     assert b.BYTES_SHARED == 3024 + 16 and b.BYTES_PBK == 3024 + 936 + 32
     assert b.HBM_PEAK_GBPS == 8000.0
 
 
 def test_cpu_baseline_leg(pkg):
     b = _bench()
-    r = b.cpu_baseline(n_target_seconds=0.05)
-    assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "blocks/s" and r["value"] > 0
-    assert "sample" in r and r["all_cores"]["cores"] >= 1
+    for pbk in (True, False):
+        r = b.cpu_baseline(pbk, n_target_seconds=0.05)
+        assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "blocks/s" and r["value"] > 0
+        assert ("per-block keys" in r["sample"]) == pbk and r["all_cores"]["cores"] >= 1
+
+
+def test_watchdog_exits_non_zero(tmp_path):
+    """A stalled phase of the N>1 tail must reach the driver as a failure: the watchdog prints the line with the phase
+    name on rank 0 and exits with status 3 (never 0)."""
+    import subprocess
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "import importlib.util\n"
+        "spec = importlib.util.spec_from_file_location('bench_mod', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "d = b.Watchdog(0, {'metric': 'x'}); d.arm('gather', 0.2); time.sleep(5); sys.exit(0)\n" % (str(ROOT), str(ROOT / "bench.py")))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, timeout=60)
+    assert out.returncode == 3
+    assert "phase 'gather' timed out" in out.stdout

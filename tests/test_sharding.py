@@ -71,3 +71,52 @@ def test_gather_columns_gloo(pkg, tmp_path, world, n, max_msg):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, pkg.LAYOUT_PACKED, tmp_path, max_msg), nprocs=world, join=True)
     assert (tmp_path / "result").read_text() == "ok"
+
+
+def _subgroup_worker(rank, world, port, tmp):
+    """Gather inside a SUBGROUP whose group ranks differ from the global ranks (global 1, 2 -> group 0, 1)."""
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        group = dist.new_group([1, 2])  # collective over all ranks
+        if rank in (1, 2):
+            g = rank - 1
+            counts, strides = [3, 2], [5, 7]
+            cols = [torch.full((counts[g] * s,), 10 * g + c, dtype=torch.uint8) for c, s in enumerate(strides)]
+            full = pkg.sharding.gather_columns(cols, counts, strides, dst=0, group=group)
+            if g == 0:
+                ok = all(torch.equal(f, torch.cat([torch.full((counts[r] * s,), 10 * r + c, dtype=torch.uint8) for r in range(2)]))
+                         for c, (f, s) in enumerate(zip(full, strides)))
+                (tmp / "sub").write_text("ok" if ok else "mismatch")
+            else:
+                assert full is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_columns_in_a_subgroup(pkg, tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_subgroup_worker, args=(3, _free_port(), tmp_path), nprocs=3, join=True)
+    assert (tmp_path / "sub").read_text() == "ok"
+
+
+def test_gather_offsets_pure_host(pkg):
+    """aesw_gather_offsets: the index math of the C-ABI gather (exclusive prefix sum), no device needed."""
+    import ctypes as C
+    lib = pkg.load_library()
+    counts = np.array([5, 0, 7, 1], np.uint64)
+    offs = np.zeros(4, np.uint64)
+    total = C.c_uint64()
+    assert lib.aesw_gather_offsets(4, counts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), C.byref(total)) == 0
+    assert offs.tolist() == [0, 5, 5, 12] and total.value == 13
+    assert lib.aesw_gather_offsets(0, counts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), None) == 1
