@@ -23,7 +23,15 @@ __global__ void __launch_bounds__(256) k_shape(uint8_t *out, size_t per, int nst
     u32x4 v = {1u, 2u, 3u, threadIdx.x};
     for (size_t p = (size_t)threadIdx.x * 16; p < chunk; p += (size_t)blockDim.x * 16) st_sc1(g + p, v);
 }
-int main() {
+// S sequential streams advancing in lockstep: workgroup i writes chunk (i % S) * (nchunks / S) + i / S
+__global__ void __launch_bounds__(256) k_lockstep(uint8_t *out, size_t nchunks, size_t S, size_t chunk) {
+    const size_t i = blockIdx.x, j = (i % S) * (nchunks / S) + i / S;
+    if (j >= nchunks) return;
+    u32x4 v = {1u, 2u, 3u, threadIdx.x};
+    uint8_t *g = out + j * chunk;
+    for (size_t p = (size_t)threadIdx.x * 16; p < chunk; p += (size_t)blockDim.x * 16) st_sc1(g + p, v);
+}
+int main(int argc, char **argv) {
     const size_t total = (size_t)4032 << 20;  // 4.2 GB = 7 x 576 MiB (also divisible by 1..4)
     uint8_t *buf[2];
     for (auto &b : buf) CK(hipMalloc(&b, total));
@@ -47,6 +55,26 @@ int main() {
                total / (ms / 6 * 1e-3) / 1e9);
         fflush(stdout);
     };
+    if (argc > 1) {  // "streams": how many sequential write streams does the memory system follow at the fill rate?
+        for (int rep = 0; rep < 2; ++rep)
+            for (size_t chunk : {(size_t)4096, (size_t)1024})
+                for (size_t S : {(size_t)1, (size_t)8, (size_t)64, (size_t)512, (size_t)2048, (size_t)8192, (size_t)32768, (size_t)131072}) {
+                    const size_t nchunks = total / chunk;
+                    const int threads = chunk >= 4096 ? 256 : 64;
+                    auto launch = [&](int i) { hipLaunchKernelGGL(k_lockstep, dim3((unsigned)nchunks), dim3(threads), 0, 0, buf[i & 1], nchunks, S, chunk); };
+                    for (int i = 0; i < 2; ++i) launch(i);
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0));
+                    for (int i = 0; i < 6; ++i) launch(i);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    printf("lockstep streams %6zu  chunk %5zu B  threads %3d   %9.2f us  %7.1f GB/s\n", S, chunk, threads, ms * 1e3 / 6, total / (ms / 6 * 1e-3) / 1e9);
+                    fflush(stdout);
+                }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         run(1, 4096, 256, 0);
         for (size_t chunk : {(size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536}) run(1, chunk, 64, 0);
