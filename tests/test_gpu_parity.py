@@ -225,11 +225,13 @@ def test_schedule_key_then_encrypt(pkg, oracle, layout):
     c.close()
 
 
-def test_xcd_remap(pkg, oracle):
-    """xcd_remap only permutes which workgroup takes which block group (any group count, incl. non-multiples of 8)."""
+@pytest.mark.parametrize("remap", [0, 1])
+def test_xcd_remap(pkg, oracle, remap):
+    """xcd_remap (default on) only permutes which workgroup takes which block group (any group count, incl. non-multiples of 8)."""
     import torch
     c = pkg.Context(0)
-    c.set_option("xcd_remap", 1)
+    assert c.get_option("xcd_remap") == 1
+    c.set_option("xcd_remap", remap)
     for n in (64 * 11 + 5, 64 * 8, 37):
         pt, keys = _inputs(n)
         for k_host in (keys[0], keys):
@@ -243,7 +245,7 @@ def test_xcd_remap(pkg, oracle):
     c.close()
 
 
-@pytest.mark.parametrize("cap", [1, 3, 512])
+@pytest.mark.parametrize("cap", [1, 3, 8, 16, 512])
 def test_group_striding(pkg, oracle, cap):
     """grid_cap < number of block groups: every workgroup walks several groups, reusing its LDS windows."""
     import torch
