@@ -80,6 +80,9 @@ SYMBOLS = {
     "aesw_encrypt_witness_stream": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P]),
     "aesw_lookup_table": (_I, [_P, _P, _P, _P, _P]),
     "aesw_last_stream_stats": (_I, [_P, _P]),
+    "aesw_assemble_advice_host": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P]),
+    "aesw_host_register": (_I, [_P, C.c_size_t]),
+    "aesw_host_unregister": (_I, [_P]),
     "aesw_assemble_advice_stream": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
     "aesw_host_alloc": (_P, [C.c_size_t]),
     "aesw_host_free": (None, [_P]),
@@ -287,6 +290,19 @@ def host_alloc(nbytes: int) -> np.ndarray:
     arr = np.frombuffer(buf, dtype=np.uint8)
     _pinned[arr.ctypes.data] = p
     return arr
+
+
+def host_register(arr: np.ndarray):
+    """Page-lock memory the caller already owns (hipHostRegister); pair with host_unregister."""
+    rc = load_library().aesw_host_register(_np_ptr(arr), arr.nbytes)
+    if rc:
+        raise AeswError(rc, "aesw_host_register")
+
+
+def host_unregister(arr: np.ndarray):
+    rc = load_library().aesw_host_unregister(_np_ptr(arr))
+    if rc:
+        raise AeswError(rc, "aesw_host_unregister")
 
 
 def host_free(arr: np.ndarray):
@@ -593,6 +609,21 @@ class Context:
         if err:
             raise err[0]
         self._check(rc, "aesw_assemble_advice_stream")
+
+    def assemble_advice_host(self, k: int, n_sets: int, witness: "Witness", key_witness, n_blocks: int, out: np.ndarray,
+                             layout: int = K.LAYOUT_PACKED, as_fr: bool = True):
+        """aesw_assemble_advice_host: all advice columns into the host array `out` ((3*n_sets+1) << k cells of 1 or 32 bytes);
+        direct DMA when `out` is page-locked (api.host_alloc / host_register)."""
+        self._torch().cuda.current_stream(self.device).synchronize()  # the slabs must be complete
+        need = ((3 * n_sets + 1) << k) * (32 if as_fr else 1)
+        if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.size < need:
+            raise ValueError("out must be a contiguous uint8 array of at least %d bytes" % need)
+        ks = KeySlab(*[t.data_ptr() for t in key_witness[:4]]) if key_witness is not None else None
+        rc = self._lib.aesw_assemble_advice_host(
+            self._h, k, n_sets, n_blocks, layout, witness.x.data_ptr(), witness.y.data_ptr(), witness.z.data_ptr(),
+            C.byref(ks) if ks is not None else None, 1 if as_fr else 0, _np_ptr(out))
+        self._check(rc, "aesw_assemble_advice_host")
+        return out
 
     def key_schedule_witness_host(self, keys: np.ndarray, layout: int = K.LAYOUT_PACKED) -> KeyWitness:
         keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 16)

@@ -969,6 +969,94 @@ int aesw_assemble_advice_stream(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
     return AESW_OK;
 }
 
+// The same columns straight into ONE host buffer (column after column): DMA directly when the buffer is page-locked
+// (aesw_host_alloc, or the host's own advice-polynomial memory after aesw_host_register), through the bounce buffers
+// otherwise.  Column j+1 is assembled while column j travels.
+int aesw_assemble_advice_host(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks, int layout, const uint8_t *d_x,
+                              const uint8_t *d_y, const uint8_t *d_z, const aesw_key_slab *ks, int as_fr, uint8_t *out) {
+    if (!out) return AESW_ERR_INVALID_ARG;
+    AssembleParams p;
+    int rc = fill_assemble_params(ctx, k, n_sets, n_blocks, layout, d_x, d_y, d_z, ks, &p);
+    if (rc != AESW_OK) return rc;
+    if (k > 28) return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    rc = ensure_streams(ctx);
+    if (rc != AESW_OK) return rc;
+    const uint64_t rows = (uint64_t)1 << k;
+    const size_t col_bytes = (size_t)rows * (as_fr ? AESW_FR_BYTES : 1);
+    const size_t slot = (col_bytes + 255) / 256 * 256;
+    const uint32_t ncols = 3 * n_sets + 1;
+    const bool direct = is_pinned(out) && is_pinned(out + (size_t)ncols * col_bytes - 1);
+    rc = ensure_scratch(ctx, 2 * slot);
+    if (rc != AESW_OK) return rc;
+    if (!direct) {
+        rc = ensure_bounce(ctx, slot);
+        if (rc != AESW_OK) return rc;
+    }
+    struct SyncGuard {
+        aesw_ctx *c;
+        ~SyncGuard() { (void)hipStreamSynchronize(c->s_copy); (void)hipStreamSynchronize(c->s_compute); }
+    } sync_guard{ctx};
+    hipEvent_t done[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    struct EvGuard {
+        hipEvent_t *a, *b;
+        ~EvGuard() { for (int i = 0; i < 2; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } }
+    } evg{done, copied};
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+    }
+    bool busy[2] = {false, false};
+    uint32_t held[2] = {0, 0};
+    auto drain = [&](int s) -> int {  // the device slot (and bounce buffer) of stage s is free again after this
+        if (!busy[s]) return AESW_OK;
+        HIP_TRY(ctx, hipEventSynchronize(copied[s]));
+        if (!direct) std::memcpy(out + (size_t)held[s] * col_bytes, ctx->bounce[s], col_bytes);
+        busy[s] = false;
+        return AESW_OK;
+    };
+    for (uint32_t col = 0; col < ncols; ++col) {
+        const int s = (int)(col & 1);
+        rc = drain(s);
+        if (rc != AESW_OK) return rc;
+        AssembleParams q = p;
+        q.col_first = col;
+        q.col_count = 1;
+        q.out = ctx->scratch + (size_t)s * slot;
+        HIP_TRY(ctx, launch_assemble(q, as_fr != 0, ctx->fr_nt, ctx->s_compute));
+        HIP_TRY(ctx, hipEventRecord(done[s], ctx->s_compute));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(direct ? out + (size_t)col * col_bytes : ctx->bounce[s], q.out, col_bytes, hipMemcpyDeviceToHost, ctx->s_copy));
+        HIP_TRY(ctx, hipEventRecord(copied[s], ctx->s_copy));
+        // the next launch into this device slot must not overtake the copy out of it
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_compute, copied[s], 0));
+        busy[s] = true;
+        held[s] = col;
+    }
+    rc = drain(0);
+    if (rc != AESW_OK) return rc;
+    return drain(1);
+}
+
+int aesw_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return AESW_ERR_INVALID_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return AESW_ERR_HIP;
+    }
+    return AESW_OK;
+}
+
+int aesw_host_unregister(void *p) {
+    if (!p) return AESW_ERR_INVALID_ARG;
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return AESW_ERR_HIP;
+    }
+    return AESW_OK;
+}
+
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout, uint8_t *w, uint8_t *kx,
                               uint8_t *ky, uint8_t *kz, uint8_t *rk) {
     if (!ctx || !valid_layout(layout)) return AESW_ERR_INVALID_ARG;

@@ -256,6 +256,17 @@ int aesw_assemble_advice_stream(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
                                 int layout, const uint8_t *d_x, const uint8_t *d_y,
                                 const uint8_t *d_z, const aesw_key_slab *d_key_slab, int as_fr,
                                 aesw_column_fn consume, void *user);
+/* The same columns into ONE host buffer, column after column ((3*n_sets+1) << k cells): the DMA goes
+ * straight into `out` when it is page-locked -- from aesw_host_alloc(), or the host's own advice
+ * polynomial memory pinned with aesw_host_register() -- and through the context's bounce buffers
+ * otherwise.  Synchronous; column j+1 is assembled while column j travels. */
+int aesw_assemble_advice_host(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_blocks,
+                              int layout, const uint8_t *d_x, const uint8_t *d_y,
+                              const uint8_t *d_z, const aesw_key_slab *d_key_slab, int as_fr,
+                              uint8_t *out);
+/* Page-lock / release memory the host already owns (hipHostRegister), so D2H lands in it directly. */
+int aesw_host_register(void *p, size_t bytes);
+int aesw_host_unregister(void *p);
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout,
                               uint8_t *w, uint8_t *kx, uint8_t *ky, uint8_t *kz, uint8_t *rk);
 /* host-pointer aesw_schedule_key_device: key is 16 host bytes, key_slab host buffers (optional) */

@@ -215,3 +215,35 @@ def test_stream_2p24_blocks_with_verifying_consumer(ctx, pkg, oracle, layout_nam
     st = ctx.last_stream_stats()
     assert st["chunks"] == n_chunks and st["bytes_to_host"] == n * sum(strides)
     assert 0 < st["kernel_ns"] < st["wall_ns"] and st["consumer_ns"] > 0
+
+
+def test_assemble_advice_host_all_buffer_kinds(ctx, pkg, oracle):
+    """aesw_assemble_advice_host into a pageable array, an aesw_host_alloc buffer and a caller-owned array pinned with
+    aesw_host_register: the whole advice matrix equals the restated synthesize() (bytes, and Fr cells through the LUT)."""
+    import torch
+    k, n_sets = 14, 2
+    n = pkg.block_capacity(k, n_sets)
+    rng = np.random.default_rng(23)
+    pt, key = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)
+    kw = ctx.schedule_key(torch.from_numpy(key).cuda(), layout=pkg.LAYOUT_PACKED, key_slab=True)
+    wit = ctx.encrypt_witness(torch.from_numpy(pt).cuda(), None, layout=pkg.LAYOUT_PACKED)
+    with oracle.circuit(k, n_sets, key, pt, record_copies=False) as c:
+        expect = np.stack([c.advice(j) for j in range(c.num_advice)])
+    lut = _fr_lut()
+    ncols = 3 * n_sets + 1
+    for as_fr in (False, True):
+        nbytes = (ncols << k) * (32 if as_fr else 1)
+        want = lut[expect].reshape(-1) if as_fr else expect.reshape(-1)
+        pageable = np.full(nbytes, 0xEE, np.uint8)
+        pinned = pkg.api.host_alloc(nbytes)
+        registered = np.full(nbytes + 4096, 0xEE, np.uint8)[:nbytes]
+        pkg.api.host_register(registered)
+        try:
+            for name, buf in (("pageable", pageable), ("aesw_host_alloc", pinned), ("aesw_host_register", registered)):
+                ctx.assemble_advice_host(k, n_sets, wit, kw, n, buf, layout=pkg.LAYOUT_PACKED, as_fr=as_fr)
+                assert np.array_equal(buf, want), "%s as_fr=%s" % (name, as_fr)
+        finally:
+            pkg.api.host_unregister(registered)
+            pkg.api.host_free(pinned)
+    with pytest.raises(ValueError):
+        ctx.assemble_advice_host(k, n_sets, wit, kw, n, np.zeros(10, np.uint8))

@@ -1,6 +1,7 @@
 /* asan_driver.c -- drives the host-side code of the library (C ABI host paths, the C++ mirror in every assign
  * mode, pure-host geometry) from plain C, for a host-only AddressSanitizer / UBSan build of libaesw
  * (hipcc ... -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined).  Exit code 0 = no finding. */
+#include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,6 +15,12 @@ static int consume(void *u, uint64_t first, uint64_t count, const uint8_t *x, co
     *sum += count + (x ? x[0] & 0 : 0) + y[count * 2 - 1] * 0 + z[count * 2 - 1] * 0 + first * 0;
     return 0;
 }
+static int on_column(void *u, uint32_t col, const uint8_t *cells, uint64_t n_cells) {
+    uint64_t *sum = (uint64_t *)u;
+    *sum += n_cells + cells[n_cells - 1] * 0 + col * 0;
+    return 0;
+}
+#define HCHECK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #e, hipGetErrorString(e_)); return 1; } } while (0)
 #define CHECK(e) do { int rc_ = (e); if (rc_ != AESW_OK) { fprintf(stderr, "%s -> %d (%s)\n", #e, rc_, aesw_strerror(rc_)); return 1; } } while (0)
 int main(void) {
     uint8_t sbox[256], mul2[256], mul3[256];
@@ -85,8 +92,62 @@ int main(void) {
     uint8_t *sel = malloc((size_t)(5 * 2 + 1) << 14), *fixed = malloc((size_t)1 << 14);
     CHECK(aesw_assemble_selectors(14, 2, 15, sel, fixed));
     free(sel); free(fixed);
-    /* the C++ mirror, every assign mode, K = 14, N = 2 holds 9 + 12 blocks */
-    for (int mode = 0; mode < 4; ++mode) {
+    {   /* device-pointer path: schedule + encrypt on a stream, whole columns streamed to the host (bytes and Fr cells),
+           the one-rank gather, the stream statistics */
+        const uint32_t k = 14, n_sets = 2;
+        const uint64_t nb = 20;
+        const int L = AESW_LAYOUT_PACKED;
+        const size_t cs[3] = {aesw_column_stride(L, 0), aesw_column_stride(L, 1), aesw_column_stride(L, 2)};
+        const size_t ks3[3] = {aesw_key_column_stride(L, 0), aesw_key_column_stride(L, 1), aesw_key_column_stride(L, 2)};
+        uint8_t *d_pt, *d_key, *d_col[3], *d_g[3], *d_w, *d_k[3];
+        hipStream_t st;
+        HCHECK(hipStreamCreate(&st));
+        HCHECK(hipMalloc((void **)&d_pt, nb * 16)); HCHECK(hipMalloc((void **)&d_key, 16)); HCHECK(hipMalloc((void **)&d_w, AESW_WORDS_ROWS));
+        for (int c = 0; c < 3; ++c) { HCHECK(hipMalloc((void **)&d_col[c], nb * cs[c])); HCHECK(hipMalloc((void **)&d_g[c], nb * cs[c])); HCHECK(hipMalloc((void **)&d_k[c], ks3[c])); }
+        HCHECK(hipMemcpy(d_pt, pt, nb * 16, hipMemcpyHostToDevice)); HCHECK(hipMemcpy(d_key, key, 16, hipMemcpyHostToDevice));
+        aesw_key_slab dks = {d_w, d_k[0], d_k[1], d_k[2]};
+        CHECK(aesw_schedule_key_device(ctx, d_key, L, &dks, st));
+        CHECK(aesw_encrypt_witness_device(ctx, d_pt, NULL, 0, nb, L, d_col[0], d_col[1], d_col[2], NULL, NULL, st));
+        aesw_comm *comm = NULL;
+        CHECK(aesw_comm_create(ctx, 1, 0, NULL, &comm));
+        const uint8_t *send[3] = {d_col[0], d_col[1], d_col[2]};
+        uint8_t *recv[3] = {d_g[0], d_g[1], d_g[2]};
+        const uint64_t counts[1] = {nb};
+        const uint32_t strides[3] = {(uint32_t)cs[0], (uint32_t)cs[1], (uint32_t)cs[2]};
+        CHECK(aesw_gather_columns_device(comm, 0, 3, send, recv, counts, strides, st));
+        if (aesw_gather_columns_device(comm, 1, 3, send, recv, counts, strides, st) != AESW_ERR_INVALID_ARG) { fprintf(stderr, "gather: bad root accepted\n"); return 1; }
+        aesw_comm_destroy(comm);
+        HCHECK(hipStreamSynchronize(st));
+        for (int as_fr = 0; as_fr < 2; ++as_fr) {
+            uint64_t sum = 0;
+            CHECK(aesw_assemble_advice_stream(ctx, k, n_sets, nb, L, d_g[0], d_g[1], d_g[2], &dks, as_fr, on_column, &sum));
+            if (sum != (uint64_t)(3 * n_sets + 1) << k) { fprintf(stderr, "assemble stream saw %llu cells\n", (unsigned long long)sum); return 1; }
+            aesw_stream_stats stt;
+            CHECK(aesw_last_stream_stats(ctx, &stt));
+            if (stt.chunks != 3 * n_sets + 1 || stt.bytes_to_host != ((uint64_t)(3 * n_sets + 1) << k) * (as_fr ? 32 : 1)) { fprintf(stderr, "stream stats wrong\n"); return 1; }
+        }
+        {   /* whole matrix into one host buffer: pageable, page-locked, and caller memory pinned with aesw_host_register */
+            const size_t bytes = (size_t)(3 * n_sets + 1) << k;
+            uint8_t *pageable = malloc(bytes), *pinned = aesw_host_alloc(bytes), *own = malloc(bytes + 4096);
+            CHECK(aesw_assemble_advice_host(ctx, k, n_sets, nb, L, d_g[0], d_g[1], d_g[2], &dks, 0, pageable));
+            CHECK(aesw_assemble_advice_host(ctx, k, n_sets, nb, L, d_g[0], d_g[1], d_g[2], &dks, 0, pinned));
+            CHECK(aesw_host_register(own, bytes));
+            CHECK(aesw_assemble_advice_host(ctx, k, n_sets, nb, L, d_g[0], d_g[1], d_g[2], &dks, 0, own));
+            CHECK(aesw_host_unregister(own));
+            if (memcmp(pageable, pinned, bytes) != 0 || memcmp(pageable, own, bytes) != 0) { fprintf(stderr, "assemble_advice_host: buffers differ\n"); return 1; }
+            free(pageable); free(own); aesw_host_free(pinned);
+        }
+        if (aesw_assemble_advice_stream(ctx, k, n_sets, 40, L, d_g[0], d_g[1], d_g[2], &dks, 0, on_column, NULL) != AESW_ERR_CAPACITY) { fprintf(stderr, "assemble stream: capacity error expected\n"); return 1; }
+        for (int c = 0; c < 3; ++c) { HCHECK(hipFree(d_col[c])); HCHECK(hipFree(d_g[c])); HCHECK(hipFree(d_k[c])); }
+        HCHECK(hipFree(d_pt)); HCHECK(hipFree(d_key)); HCHECK(hipFree(d_w));
+        HCHECK(hipStreamDestroy(st));
+        uint64_t offs[3], total = 0;
+        const uint64_t cnt3[3] = {4, 0, 9};
+        CHECK(aesw_gather_offsets(3, cnt3, offs, &total));
+        if (offs[2] != 4 || total != 13) { fprintf(stderr, "gather offsets wrong\n"); return 1; }
+    }
+    /* the C++ mirror, every assign mode (0 packed, 1 bulk, 2 values, 3 streaming, 4 dense), K = 14, N = 2 holds 9 + 12 blocks */
+    for (int mode = 0; mode < 5; ++mode) {
         aesw_host_circuit *hc = NULL;
         const int rc = aesw_host_aes_circuit_run(ctx, 14, 2, key, pt, 20, 1, 0, mode, &hc);
         if (rc != AESW_OK) { fprintf(stderr, "circuit_run mode %d -> %d: %s\n", mode, rc, aesw_host_last_error()); return 1; }
