@@ -419,12 +419,12 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
 // Waves per group when the option is 0 (auto): as many 16-block waves as keep
 // 6-8 waves resident per CU given the LDS windows (DESIGN.md "occupancy").
 static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
-    // per-block keys: 3-wave groups (2 per CU) measured 3-4 % ahead of 2- and 1-wave groups at 2^20 blocks on two
-    // boxes (tools/sweep.py 20 c2 packed waves); dense: 1..3 equal, 4 slower
     // upper bound: a group's staging must stay below 64 KiB (16-bit LDS addresses in the flush descriptors)
     const int max_waves = layout == AESW_LAYOUT_DENSE ? 2 : layout == AESW_LAYOUT_VALUES ? 4 : 3;
     int w;
-    if (pbk) w = ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_DENSE ? 1 : 3);
+    // per-block keys: one-wave groups (7 resident per CU instead of two 3-wave groups) measured +1.3 ... +2.4 % at 2^20
+    // blocks on two boxes and -0.6 % on a third (tools/sweep.py 20 c2 packed waves); shared key: 3-wave groups
+    if (pbk) w = ctx->waves_pbk ? ctx->waves_pbk : 1;
     else w = ctx->waves_shared ? ctx->waves_shared : (layout == AESW_LAYOUT_DENSE ? 2 : 3);
     return w > max_waves ? max_waves : w;
 }

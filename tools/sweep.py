@@ -23,6 +23,10 @@ if len(sys.argv) > 4 and sys.argv[4] == "cap":
     for w in (4, 3, 2):
         for cap in (0, 256 * (8 // w), 256 * (8 // w) * 3 // 2, 256 * (8 // w) // 2):
             variants.append({"waves_shared": w, "waves_pbk": w, "grid_cap": cap})
+elif len(sys.argv) > 4 and sys.argv[4] == "cap3":
+    for w in (3, 1):
+        for cap in (0, 256, 512, 768, 1024, 2048):
+            variants.append({"waves_shared": w, "waves_pbk": w, "grid_cap": cap * (3 // w)})
 elif len(sys.argv) > 4 and sys.argv[4] == "waves":
     for w in (4, 3, 2, 1):
         variants.append({"waves_shared": w, "waves_pbk": w})
