@@ -247,3 +247,52 @@ def test_assemble_advice_host_all_buffer_kinds(ctx, pkg, oracle):
             pkg.api.host_free(pinned)
     with pytest.raises(ValueError):
         ctx.assemble_advice_host(k, n_sets, wit, kw, n, np.zeros(10, np.uint8))
+
+
+def test_gather_call_sequence_for_three_ranks(pkg, tmp_path):
+    """The multi-rank leg of aesw_gather_columns_device against a RECORDING stand-in for librccl (tests/mock_rccl/; no
+    multi-GPU box is available to the builder): as root of 3 ranks it posts, inside ONE group, receives from ranks 1 and 2
+    at their block offsets in pieces of at most max_message bytes and nothing for itself; as rank 2 it sends its range of
+    every column to the root in the same pieces.  ncclUint8 everywhere."""
+    import os
+    mock_dir = ROOT / "tests" / "mock_rccl"
+    lib_dir = ROOT / "halo2-aes_amd"
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-o", str(tmp_path / "librccl.so"), str(mock_dir / "mock_rccl.c")], check=True)
+    exe = tmp_path / "gather_driver"
+    subprocess.run(["gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I", str(ROOT / "include"), "-I", "/opt/rocm/include",
+                    str(mock_dir / "gather_driver.c"), "-o", str(exe), "-L", str(lib_dir), "-laesw", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    counts, strides, maxmsg = [5, 3, 7], [1360, 1056, 608], 4000
+    offs = [0, 5, 8]
+
+    def run(rank):
+        log = tmp_path / ("log%d" % rank)
+        env = dict(os.environ, MOCK_RCCL_LOG=str(log), LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        out = subprocess.run([str(exe), "3", str(rank), str(maxmsg)] + [str(c) for c in counts], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stdout
+        base = {}
+        for line in out.stdout.splitlines():
+            if line.startswith("col"):
+                _, c, _, s, _, r = line.split()
+                base[int(c)] = (int(s), int(r))
+        calls = [l.split() for l in log.read_text().splitlines()]
+        return base, calls
+
+    def pieces(nbytes):
+        return [(o, min(maxmsg, nbytes - o)) for o in range(0, nbytes, maxmsg)]
+
+    base, calls = run(0)
+    assert calls[0][0] == "id" and calls[1][:3] == ["init", "3", "0"] and calls[1][3] == str(0x5a)
+    body = calls[2:-1]
+    assert body[0][0] == "group_start" and body[-1][0] == "group_end" and calls[-1][0] == "destroy"
+    expect = []
+    for c, s in enumerate(strides):
+        for peer in (1, 2):
+            for o, m in pieces(counts[peer] * s):
+                expect.append(["recv", str(peer), str(base[c][1] + offs[peer] * s + o), str(m)])
+    assert body[1:-1] == expect
+    base, calls = run(2)
+    body = calls[2:-1]
+    expect = [["send", "0", str(base[c][0] + o), str(m)] for c, s in enumerate(strides) for o, m in pieces(counts[2] * s)]
+    assert body[0][0] == "group_start" and body[-1][0] == "group_end" and body[1:-1] == expect
