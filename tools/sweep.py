@@ -34,7 +34,7 @@ elif len(sys.argv) > 4 and sys.argv[4] == "cap4":
     for cap in (0, 128, 192, 224, 256, 288, 320, 384, 512):
         variants.append({"waves_shared": 4, "waves_pbk": 4, "grid_cap": cap})
 elif len(sys.argv) > 4 and sys.argv[4] == "store":
-    for w in (4, 2):
+    for w in (3, 1):
         for m in (0, 1, 2):
             variants.append({"waves_shared": w, "waves_pbk": w, "store_mode": m})
 elif len(sys.argv) > 4 and sys.argv[4] == "xcd":
