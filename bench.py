@@ -589,7 +589,8 @@ def main():
             dog.disarm()
             if rank == 0:
                 line["gather"] = {"seconds": dt, "GBps_into_root": (world - 1) * n * sum(strides) / dt / 1e9,
-                                  "note": "aesw_gather_columns_device: RCCL send/recv of per-rank column ranges to rank 0 over xGMI, outside `value`"}
+                                  "path": pkg.sharding.last_gather_path,
+                                  "note": "per-rank column ranges gathered on rank 0, outside `value`"}
         except Exception as e:
             dog.disarm()
             if rank == 0:
@@ -615,6 +616,7 @@ def main():
                                   "launch_ms": float(t3[1]),
                                   "achieved_GBps_per_gpu": BYTES_SHARED * n3 / (float(t3[1]) * 1e-3) / 1e9,
                                   "gather_seconds": dt3, "gather_GBps_into_root": (world - 1) * n3 * sum(strides) / dt3 / 1e9,
+                                  "gather_path": pkg.sharding.last_gather_path,
                                   "note": "generation and gather timed separately; the gather is bound by the root's xGMI ingest"}
                 del r3
             except Exception as e:

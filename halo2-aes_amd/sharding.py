@@ -27,6 +27,7 @@ def shard_sizes(n: int, world: int) -> List[int]:
 
 
 _comms = {}  # (id of ctx, group) -> api.Comm
+last_gather_path = None  # "aesw_gather_columns_device (RCCL)" or "torch.distributed point-to-point": what the last call used
 
 
 def _aesw_comm(ctx, group):
@@ -74,10 +75,13 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
         raise ValueError("counts/strides do not match world size / columns")
     if max_message_bytes <= 0:
         raise ValueError("max_message_bytes must be positive")
+    global last_gather_path
     if ctx is not None and dist.get_backend(group) == "nccl" and all(c.is_cuda for c in columns):
+        last_gather_path = "aesw_gather_columns_device (RCCL send/recv over xGMI, C ABI)"
         comm = _aesw_comm(ctx, group)
         comm.set_max_message(max_message_bytes)
         return comm.gather_columns([c[:counts[rank] * s] for c, s in zip(columns, strides)], counts, strides, root=dst)
+    last_gather_path = "torch.distributed point-to-point (%s)" % dist.get_backend(group)
     total = sum(counts)
     offs = [sum(counts[:r]) for r in range(world)]
     peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)  # P2POp wants global ranks
