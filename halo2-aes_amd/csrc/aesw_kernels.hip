@@ -6,13 +6,15 @@
 //   lane  = one state column (4 packed bytes) of one AES block
 //   quad  = one block: ShiftRows is three DPP quad_perm moves, no LDS
 //   wave  = 16 blocks; it owns a private LDS staging slab and needs no barrier
-//   group = WAVES waves = 16*WAVES consecutive blocks (64 by default, so a
-//           group's output range is 128-byte-line aligned in every column)
+//   group = WAVES waves = 16*WAVES consecutive blocks (1..3 waves; every wave's
+//           16-block output range is 128-byte-line aligned in every column)
 // Data flow per wave: registers -> whole dwords (v_perm_b32) -> per-block LDS
 // staging windows (aesw_layout.h Win<>: permanent head + round slots,
 // bank-conflict-free strides) -> after every round, the 128-byte lines of the
 // output columns that just became complete leave as whole lines, 8 lanes x 16 B
-// per line, 8 lines per store instruction.  Partial-line stores are what caps a
+// per line, 8 lines per store instruction, following a fixed schedule whose
+// per-lane descriptors (LDS address | global offset) sit in registers
+// (aesw_layout.h "scheduled flush").  Partial-line stores are what caps a
 // naive per-round flush at ~3 TB/s; whole lines reach ~5.5 TB/s (tools/storebench).
 // The S-box / mul2 / mul3 tables live in LDS (768 B); when the host's mul
 // tables equal GF(2^8) xtime the packed arithmetic path replaces 8 of the 12
