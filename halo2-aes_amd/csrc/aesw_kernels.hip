@@ -152,7 +152,8 @@ __device__ __forceinline__ uint8_t *uniform_ptr(uint8_t *p) {
 //   bits 0..15  LDS address of the lane's 16-byte piece      bits 16..30  byte offset in the wave's global range
 // Round R issues all its ds_read_b128 first (their LDS round trips overlap), then the stores: 8 whole lines per
 // instruction.  FULL (16 valid blocks, the common case): only the last instruction of a round can have unused
-// slots, known at compile time; otherwise every piece is predicated with "offset < nvalid * stride".
+// slots (known at compile time whether it has); it and every piece of a partial wave are predicated with
+// "offset < nvalid * stride", which unused slots (offset 0x7ff0) fail too.
 template <class W, bool ON>
 struct ColSched {
     static constexpr int N = ON ? sched_first<W>(10) : 0;
@@ -176,12 +177,14 @@ struct RoundBatch {
         }
     }
     template <int NT, bool FULL, class CS>
-    __device__ __forceinline__ void store(uint8_t *g, const CS &cs, uint32_t limit, int lane) const {
+    __device__ __forceinline__ void store(uint8_t *g, const CS &cs, uint32_t limit) const {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const uint32_t off = cs.d[FIRST + i] >> 16;
-            constexpr int last_slots = NLINES - 8 * (NI - 1);  // line slots in use in the round's last instruction
-            const bool ok = !FULL ? off < limit : (i == NI - 1 && last_slots < 8) ? lane < 8 * last_slots : true;
+            // unused line slots (offset 0x7ff0) exist only in a round's last instruction, and only when the round's
+            // line count is not a multiple of 8: every other instruction of a full wave stores unconditionally
+            constexpr bool last_partial = NLINES % 8 != 0;
+            const bool ok = (!FULL || (last_partial && i == NI - 1)) ? off < limit : true;
             if (ok) gstore_at<NT>(g, off, v[i]);
         }
     }
@@ -198,7 +201,7 @@ struct Scheds {
 
 template <int L, int NT, int R, bool FULL>
 __device__ __forceinline__ void flush_round(const uint8_t *lds, uint8_t *gx, uint8_t *gy, uint8_t *gz, const Scheds<L> &sc,
-                                            int nvalid, int lane) {
+                                            int nvalid) {
     if (NT == 3) return;  // -DAESW_DIAGNOSTIC builds only (store_mode 3): price the flush by leaving it out
     RoundBatch<WinX<L>, R> bx;
     RoundBatch<WinY<L>, R> by;
@@ -206,9 +209,9 @@ __device__ __forceinline__ void flush_round(const uint8_t *lds, uint8_t *gx, uin
     if (Geo<L>::HAS_X) bx.template load<NT>(lds, sc.x);
     by.template load<NT>(lds, sc.y);
     bz.template load<NT>(lds, sc.z);
-    if (Geo<L>::HAS_X) bx.template store<NT, FULL>(gx, sc.x, (uint32_t)nvalid * Geo<L>::XS, lane);
-    by.template store<NT, FULL>(gy, sc.y, (uint32_t)nvalid * Geo<L>::YS, lane);
-    bz.template store<NT, FULL>(gz, sc.z, (uint32_t)nvalid * Geo<L>::ZS, lane);
+    if (Geo<L>::HAS_X) bx.template store<NT, FULL>(gx, sc.x, (uint32_t)nvalid * Geo<L>::XS);
+    by.template store<NT, FULL>(gy, sc.y, (uint32_t)nvalid * Geo<L>::YS);
+    bz.template store<NT, FULL>(gz, sc.z, (uint32_t)nvalid * Geo<L>::ZS);
 }
 
 // Fully contiguous: nvalid*STRIDE bytes from LDS stage to g.
@@ -490,7 +493,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
                     ptw_next = load_word(a.pt, grp + gridDim.x);
                     if (PBK) kw_next = load_word(a.keys, grp + gridDim.x);
                 }
-                flush_round<L, NT, R, FULL>(lds, gx, gy, gz, sc, nvalid, lane);
+                flush_round<L, NT, R, FULL>(lds, gx, gy, gz, sc, nvalid);
                 wave_lds_fence();
                 if (R == 1) AESW_TRACE_POINT(3);
                 if (R == 5) AESW_TRACE_POINT(4);

@@ -4,6 +4,7 @@
 // with the cross-lane steps (DPP quad permutes) and LDS replaced by arrays.
 // TEST INFRASTRUCTURE: lets `-m "not gpu"` tests compare the device program
 // with the oracle before any GPU run.  Not reachable from the product library.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -78,7 +79,11 @@ int flush_forms_disagree() {
                 for (int lane = 0; lane < 64; ++lane) {
                     const uint32_t d = tab.t[(size_t)i * 64 + lane], off = d >> 16;
                     if (off < (uint32_t)nvalid * W::GSTRIDE) got[off / 16] = (int)(d & 0xffffu) | (R << 20);
-                    if (d != sched_descriptor<W>(R, i - sched_first<W>(R), lane)) bad++;  // table == constexpr form
+                    // eight lanes = one whole 128-byte line; unused slots only in a round's last instruction, and only
+                    // when the round's line count is not a multiple of 8 (the kernel predicates just that instruction)
+                    if ((d >> 16) != SCHED_INVALID_P && ((d >> 16) & 127) != 16u * (lane & 7)) bad++;
+                    if ((d >> 16) != SCHED_INVALID_P && (d >> 16) != (tab.t[(size_t)i * 64 + (lane & ~7)] >> 16) + 16u * (lane & 7)) bad++;
+                    if ((d >> 16) == SCHED_INVALID_P && (i != sched_first<W>(R + 1) - 1 || sched_nlines<W>(R) % 8 == 0)) bad++;
                 }
         for (int p = 0; p < npieces; ++p) bad += spec[p] != got[p];
     }
@@ -211,6 +216,35 @@ extern "C" int lane_model_flush_not_exactly_once(void) {
     return flush_not_exactly_once<WinX<DENSE>>() + flush_not_exactly_once<WinY<DENSE>>() + flush_not_exactly_once<WinZ<DENSE>>() +
            flush_not_exactly_once<WinX<PACKED>>() + flush_not_exactly_once<WinY<PACKED>>() + flush_not_exactly_once<WinZ<PACKED>>() +
            flush_not_exactly_once<WinY<VALUES>>() + flush_not_exactly_once<WinZ<VALUES>>();
+}
+
+// LDS bank-conflict cost (extra cycles per wave) of the flush reads: the table as built, and the same lines in plain
+// address order, for the packed layout's three columns.
+template <class W>
+static void conflict_costs(int *built, int *sorted) {
+    const ColTable<W> tab;
+    *built += flush_table_conflict_cost<W>(tab.t.data());
+    std::vector<uint32_t> plain(tab.t.size());
+    int idx = 0;
+    for (int R = 1; R <= 9; ++R) {
+        std::vector<uint32_t> entries;  // the round's line slots in address order
+        for (int i = sched_first<W>(R); i < sched_first<W>(R + 1); ++i)
+            for (int slot = 0; slot < 8; ++slot)
+                if ((tab.t[(size_t)i * 64 + 8 * slot] >> 16) != SCHED_INVALID_P) entries.push_back((uint32_t)(i * 8 + slot));
+        std::sort(entries.begin(), entries.end(), [&](uint32_t a, uint32_t b) { return (tab.t[(size_t)a * 8] >> 16) < (tab.t[(size_t)b * 8] >> 16); });
+        for (int i = sched_first<W>(R); i < sched_first<W>(R + 1); ++i, ++idx)
+            for (int lane = 0; lane < 64; ++lane) {
+                const size_t slot = (size_t)(i - sched_first<W>(R)) * 8 + (lane >> 3);
+                plain[(size_t)i * 64 + lane] = slot < entries.size() ? tab.t[(size_t)entries[slot] * 8 + (lane & 7)] : (SCHED_INVALID_P << 16);
+            }
+    }
+    *sorted += flush_table_conflict_cost<W>(plain.data());
+}
+extern "C" void lane_model_flush_conflict_costs(int layout, int *built, int *sorted) {
+    *built = *sorted = 0;
+    if (layout == PACKED) { conflict_costs<WinX<PACKED>>(built, sorted); conflict_costs<WinY<PACKED>>(built, sorted); conflict_costs<WinZ<PACKED>>(built, sorted); }
+    else if (layout == DENSE) { conflict_costs<WinX<DENSE>>(built, sorted); conflict_costs<WinY<DENSE>>(built, sorted); conflict_costs<WinZ<DENSE>>(built, sorted); }
+    else { conflict_costs<WinY<VALUES>>(built, sorted); conflict_costs<WinZ<VALUES>>(built, sorted); }
 }
 
 extern "C" int lane_model_flush_forms_disagree(void) {
