@@ -69,6 +69,21 @@ def test_random_circuit_two_sets(ctx, pkg, oracle):
                 assert np.array_equal(mock.ciphertext(b), o.ciphertext(b))
 
 
+def test_dense_witness_is_still_an_option(ctx, pkg, oracle):
+    """assign_mode 4: the mirror fed by the AESW_LAYOUT_DENSE witness (the default is PACKED since round 2) builds the
+    same circuit, and a tampered cell is still caught through either layout."""
+    rng = np.random.default_rng(77)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (40, 16), dtype=np.uint8)
+    with pkg.HostCircuit.aes(ctx, 16, 2, key, pts, dense=True) as mock, oracle.circuit(16, 2, key, pts) as o:
+        rc, msg = mock.verify()
+        assert rc == 0, msg
+        _same_assembly(mock, o)
+        mock.poke(2, 400 + 31, int(mock.advice(2)[400 + 31]) ^ 1)   # z of the first block's last AddRoundKey row
+        rc, msg = mock.verify()
+        assert rc == 8 and msg
+
+
 def test_values_only_witness_fills_the_whole_circuit(ctx, pkg, oracle):
     """AESW_LAYOUT_VALUES hands the host only the S-box / mul / xor outputs (1 056 B per block).  Running the
     reference's regions on it -- copy_advice() carrying every other value, as in the reference -- must assign
