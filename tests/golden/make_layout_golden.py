@@ -30,23 +30,29 @@ def runs(v):
     return [[int(a), int(b - a)] for a, b in zip(s, e)]
 
 
-def extract(name, n_columns, n_advice, k):
+def extract(name, n_columns, n_advice, k, fixed_from):
+    """advice columns 0..n_advice-1, then the fixed column and the selector columns (the four lookup-table columns in
+    between are drawn as one table region, not cell by cell, and carry no information)"""
     a = np.array(Image.open(REF / name).convert("RGB"))
     assert a.shape == (32768, 2048, 3)
     black = (a == 0).all(axis=2)
     cw = 2048 / n_columns
-    cols = []
-    for c in range(n_advice):
+    cols, fixed = [], []
+    for c in range(n_columns):
         x = int((c + 0.5) * cw)  # the middle of the column: away from the region borders
-        cols.append({"x": x, "black_runs": runs(black[Y0:Y0 + H, x])})
+        entry = {"x": x, "black_runs": runs(black[Y0:Y0 + H, x])}
+        if c < n_advice:
+            cols.append(entry)
+        elif c >= fixed_from:
+            fixed.append(entry)
     return {"image": name, "size": [2048, 32768], "title_rows": Y0, "pixel_rows": H, "k": k, "n_columns": n_columns,
-            "n_advice": n_advice, "columns": cols}
+            "n_advice": n_advice, "columns": cols, "fixed_and_selectors": fixed}
 
 
 def main():
     out = {"note": "black = assigned cell in halo2 dev-graph CircuitLayout; extracted by tests/golden/make_layout_golden.py",
-           "key_schedule": extract("key-schedule-layout.png", 13, 4, 17),
-           "aes128": extract("aes128-layout.png", 23, 7, 19)}
+           "key_schedule": extract("key-schedule-layout.png", 13, 4, 17, 8),
+           "aes128": extract("aes128-layout.png", 23, 7, 19, 11)}
     OUT.write_text(json.dumps(out, separators=(",", ":")))
     print("wrote", OUT, OUT.stat().st_size, "bytes")
 

@@ -105,3 +105,62 @@ def test_blocks_per_set_of_the_rendered_revision():
     last = max(s + n for s, n in g["columns"][3]["black_runs"] if s + n < H - 24)   # x column of set 1
     rows = last * (1 << g["k"]) / H
     assert abs(rows - 385 * 1360) <= 2 * (1 << g["k"]) / H
+
+
+def _slab_selectors(oracle):
+    """Per slab row, which chip's selector the restated synthesize() enables: [range, xor, sbox, mul2, mul3] for the
+    1360 rows of a block and the 400 key rows, q_eq_rcon and the fixed column for the 96 rows of words_column."""
+    with oracle.circuit(12, 1, np.zeros(16, np.uint8), np.zeros((1, 16), np.uint8), record_copies=False) as c:
+        sel = [c.selector(i) for i in range(c.num_selectors)]
+        fixed = c.fixed()
+    enc = [s[400:400 + 1360].astype(bool) for s in sel[:5]]
+    key = [s[:400].astype(bool) for s in sel[:5]]
+    return enc, key, sel[5][:96].astype(bool), fixed[:96] != 0
+
+
+def test_aes128_png_selector_columns(oracle):
+    """The eleven selector columns and the fixed column of the rendering: [range, xor, sbox, mul2, mul3] per column set
+    (configure()'s order, src/aes128.rs:63-68), then q_eq_rcon (src/key_schedule.rs:50).  A selector cell is black where
+    the selector is enabled, so this pins WHICH chip sits on the rows of a slab at the picture's resolution (16 rows per
+    pixel): the S-box, xor and range rows of every round and how many mul-by-2 / mul-by-3 rows each stretch of lcon() records
+    holds (src/aes128.rs:228-248, :268-301)."""
+    g = G["aes128"]
+    H, k = g["pixel_rows"], g["k"]
+    cols = g["fixed_and_selectors"]
+    assert len(cols) == 12
+    enc, key, q, fx = _slab_selectors(oracle)
+
+    def placed(s, t, block=None):
+        m = np.zeros(1 << k, bool)
+        base = 400 if s == 0 else 0
+        if s == 0:
+            m[:400] = key[t]
+        e = enc[t] if block is None else block
+        for b in range(385):
+            m[base + 1360 * b:base + 1360 * (b + 1)] = e
+        return m
+
+    w = np.zeros(1 << k, bool)
+    w[:96] = fx
+    assert _diff(w, k, cols[0], H) <= 1                                   # round constants in the fixed column
+    for s in range(2):
+        for t in range(5):
+            d = _diff(placed(s, t), k, cols[1 + 5 * s + t], H)
+            assert d <= 12, "set %d selector %d: %d pixels differ" % (s, t, d)
+    w[:96] = q
+    assert _diff(w, k, cols[11], H) <= 1
+    # sensitivity: mul2 and mul3 exchanged breaks ~860 pixels of each column.  (What 16 rows per pixel can NOT tell apart
+    # is the order of the lcon() records inside a round: word-major vs matrix-row-major moves the mul rows by < 4 rows.)
+    assert _diff(placed(0, 3, enc[4]), k, cols[4], H) > 400 and _diff(placed(0, 4, enc[3]), k, cols[5], H) > 400
+
+
+def test_key_schedule_png_selector_columns(oracle):
+    g = G["key_schedule"]
+    H, k = g["pixel_rows"], g["k"]
+    cols = g["fixed_and_selectors"]
+    assert len(cols) == 5                                                # fixed, range, xor, sbox, q_eq_rcon
+    _, key, q, fx = _slab_selectors(oracle)
+    for col, mask in zip(cols, (fx, key[0], key[1], key[2], q)):
+        m = np.zeros(1 << k, bool)
+        m[:len(mask)] = mask
+        assert _diff(m, k, col, H) <= 3
