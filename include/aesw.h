@@ -307,9 +307,11 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
                                const uint32_t *strides, void *stream);
 
 /* ---- tuning / introspection (bench.py, tests) ----------------------------- */
-/* name: "waves_shared" / "waves_pbk" (waves per group, 0 = auto, 1..4),
- * "store_mode" (0 plain, 1 nontemporal, 2 write-through sc1), "nt_stores" (0/1), "grid_cap" (max workgroups per launch, 0 = one per block
- * group), "xcd_remap" (0/1), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
+/* name: "waves_shared" / "waves_pbk" (waves per group for launches with one key / with per-block keys; 0 = auto, 1..4,
+ * silently limited to what keeps a group's LDS staging below 64 KiB: 3 for the packed layout, 2 dense, 4 values-only),
+ * "store_mode" (0 plain, 1 nontemporal, 2 write-through sc1: the default), "nt_stores" (0/1), "grid_cap" (max workgroups per launch,
+ * 0 = one per block group), "xcd_remap" (0/1, default 1: workgroups that share an XCD take one contiguous eighth of the block
+ * groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
  * pipeline, default 2^15), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1).
  * Unknown -> INVALID_ARG */
