@@ -32,6 +32,8 @@ struct aesw_ctx {
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
     int nt = 2;  // store flavour: 0 plain, 1 nontemporal, 2 write-through (sc1, default: nothing left dirty in L2 at kernel end)
     int key_nt = 1;  // store flavour of key_kernel (one contiguous flush per column at the end): nontemporal 4-9 % ahead of sc1 (tools/keysweep.py)
+    int fr_geo = 1;  // geometry of expand_fr: 1 = one-shot 4 KiB workgroups, LUT gathered from global memory: 7.3 TB/s with nontemporal stores
+                     // against 5.2 for 0 = striding workgroups + LDS LUT and 5.9 for 2 = one-shot 16 KiB + LDS LUT (tools/frsweep.py)
     int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
     bool xcd_remap = true;  // workgroups that share an XCD take one contiguous eighth of the block groups: +3-4 % at 2^20 blocks (tools/sweep.py xcd)
@@ -390,6 +392,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
         return AESW_OK;
     }
     if (!std::strcmp(name, "key_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->key_nt = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "fr_geometry")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_geo = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "fr_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_nt = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
@@ -576,7 +579,7 @@ int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cell
     if (!d_cells || !d_fr || !aligned16(d_fr)) return AESW_ERR_INVALID_ARG;
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
-    HIP_TRY(ctx, launch_expand_fr(d_cells, n_cells, ctx->d_fr_lut, d_fr, ctx->fr_nt, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_expand_fr(d_cells, n_cells, ctx->d_fr_lut, d_fr, ctx->fr_nt, ctx->fr_geo, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 

@@ -58,6 +58,6 @@ struct AssembleParams {
     int packed;
 };
 hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int store_mode, hipStream_t s);
-hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int store_mode, hipStream_t s);
+hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int store_mode, int geometry, hipStream_t s);
 
 }  // namespace aesw

@@ -598,6 +598,38 @@ __global__ void __launch_bounds__(256) expand_fr_kernel(const uint8_t *__restric
     }
 }
 
+// One-shot geometries of the same expansion (round 2, profiles/r02_study: a stream of short-lived workgroups that each
+// write a small contiguous chunk in address order is what the memory system writes fastest).
+// GEO 1: a workgroup writes 4 KiB (one 16-byte piece per thread, one store per wave) and exits; the LUT is gathered
+//        from global memory (8 KiB, L1/L2 resident).  GEO 2: 16 KiB per workgroup, LUT staged in LDS.
+template <int NT, int GEO>
+__global__ void __launch_bounds__(256) expand_fr_oneshot_kernel(const uint8_t *__restrict__ cells, uint64_t n_cells,
+                                                               const u32x4 *__restrict__ fr_lut, u32x4 *__restrict__ out) {
+    const uint64_t total = n_cells * 2;
+    if (GEO == 1) {
+        const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i >= total) return;
+        const uint32_t v = cells[i >> 1];
+        gstore<NT>(&out[i], fr_lut[v * 2 + (uint32_t)(i & 1)]);
+    } else {
+        __shared__ u32x4 lut[512];
+        for (int i = threadIdx.x; i < 512; i += 256) lut[i] = fr_lut[i];
+        const uint64_t base = (uint64_t)blockIdx.x * 1024;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = base + j * 256 + threadIdx.x;
+            v[j] = i < total ? cells[i >> 1] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = base + j * 256 + threadIdx.x;
+            if (i < total) gstore<NT>(&out[i], lut[v[j] * 2 + (uint32_t)(i & 1)]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // full advice columns of a K/N circuit (bytes or Fr cells)
 // ---------------------------------------------------------------------------
@@ -629,6 +661,9 @@ __device__ __forceinline__ uint32_t advice_cell(const AssembleParams &a, uint32_
     return idx >= 0 ? sc[b * stride + idx] : 0u;
 }
 
+// (A one-shot geometry like expand_fr's was tried for this kernel in round 2 and is 9x SLOWER: a piece here is a chain of
+// three dependent loads -- packed-index table, slab byte, LUT -- behind 64-bit divisions, and a thread with a single piece
+// has nothing to overlap them with; the striding loop below lets the compiler keep several pieces in flight per lane.)
 template <bool AS_FR, int NT>
 __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
     __shared__ u32x4 lut[AS_FR ? 512 : 1];
@@ -826,8 +861,21 @@ hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int nt, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int nt, hipStream_t s) {
+template <int GEO>
+static hipError_t launch_expand_fr_oneshot(const uint8_t *cells, uint64_t n_cells, const u32x4 *lut, u32x4 *o, int nt, hipStream_t s) {
+    const uint64_t per = GEO == 1 ? 256 : 1024;
+    const uint64_t blocks = (n_cells * 2 + per - 1) / per;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (nt == 2) hipLaunchKernelGGL((expand_fr_oneshot_kernel<2, GEO>), dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells, lut, o);
+    else if (nt == 1) hipLaunchKernelGGL((expand_fr_oneshot_kernel<1, GEO>), dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells, lut, o);
+    else hipLaunchKernelGGL((expand_fr_oneshot_kernel<0, GEO>), dim3((unsigned)blocks), dim3(256), 0, s, cells, n_cells, lut, o);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int nt, int geometry, hipStream_t s) {
     if (n_cells == 0) return hipSuccess;
+    if (geometry == 1) return launch_expand_fr_oneshot<1>(cells, n_cells, reinterpret_cast<const u32x4 *>(fr_lut), reinterpret_cast<u32x4 *>(out), nt, s);
+    if (geometry == 2) return launch_expand_fr_oneshot<2>(cells, n_cells, reinterpret_cast<const u32x4 *>(fr_lut), reinterpret_cast<u32x4 *>(out), nt, s);
     uint64_t blocks = (n_cells * 2 + 256 * 8 - 1) / (256 * 8);
     if (blocks > 256 * 8) blocks = 256 * 8;
     const u32x4 *lut = reinterpret_cast<const u32x4 *>(fr_lut);
