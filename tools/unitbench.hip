@@ -14,6 +14,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 struct Streams {
+    int flavour;  // 0 plain, 1 nontemporal, 2 sc1
     int xcd;  // 1: workgroups that share an XCD (blockIdx % 8) take one contiguous eighth of the groups
     int ns;
     uint8_t *base[7];
@@ -25,9 +26,13 @@ __device__ __forceinline__ uint32_t group_of(const Streams &s, uint32_t id, uint
     const uint32_t q = ngroups / 8, r = ngroups % 8, x = id % 8;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
 }
-__device__ __forceinline__ void st_sc1(uint8_t *p, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+__device__ int g_flavour_dev;  // unused; the flavour travels in Streams.flavour
+__device__ __forceinline__ void st_f(uint8_t *p, u32x4 v, int flavour) {
+    if (flavour == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    else if (flavour == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+    else *reinterpret_cast<u32x4 *>(p) = v;
 }
+#define st_sc1(p, v) st_f((p), (v), s.flavour)
 
 // one-shot unit: spin, then burst every stream's nb*stride bytes
 __global__ void __launch_bounds__(256) k_unit(Streams s, uint64_t nblk, int nb, int spin) {
@@ -120,13 +125,13 @@ __global__ void __launch_bounds__(256) k_fronts(Streams s, uint64_t nblk, int nb
 }
 
 // linear fill: workgroup i writes the 4 KB chunk i of one buffer
-__global__ void __launch_bounds__(256) k_fill(uint8_t *out, size_t total) {
+__global__ void __launch_bounds__(256) k_fill(uint8_t *out, size_t total, int flavour = 2) {
     const size_t p = (size_t)blockIdx.x * 4096 + (size_t)threadIdx.x * 16;
     u32x4 v = {1u, 2u, 3u, threadIdx.x};
-    if (p < total) st_sc1(out + p, v);
+    if (p < total) st_f(out + p, v, flavour);
 }
 
-static int g_xcd = 0;
+static int g_xcd = 0, g_flavour = 2;
 int main(int argc, char **argv) {
     const int only_lg = argc > 1 ? atoi(argv[1]) : 0;
     const bool quick = argc > 2 && !strcmp(argv[2], "quick");  // few variants, few launches: for rocprofv3 --pmc passes
@@ -166,13 +171,14 @@ int main(int argc, char **argv) {
                 const size_t sl = (size_t)i % (slots * 2);
                 uint8_t *b = buf[sl / slots] + (sl % slots) * bytes;
                 Streams s;
+                s.flavour = g_flavour;
                 s.xcd = g_xcd;
                 s.ns = ns;
                 for (int c = 0; c < 7; ++c) { s.base[c] = nullptr; s.stride[c] = 0; }
                 for (int c = 0; c < ns; ++c) { s.base[c] = b; s.stride[c] = S[c]; b += nblk * S[c]; }
                 return s;
             };
-            const bool fronts_only = argc > 2 && (!strcmp(argv[2], "fronts") || !strcmp(argv[2], "rank"));
+            const bool fronts_only = argc > 2 && (!strcmp(argv[2], "fronts") || !strcmp(argv[2], "rank") || !strcmp(argv[2], "flavour"));
             if (!fronts_only) {
                 const double us = timeit(reps, [&](int i) {
                     const size_t sl = (size_t)i % (slots * 2);
@@ -214,6 +220,38 @@ int main(int argc, char **argv) {
                         printf("ns %d lg %2d  linear 4 KB fill                                          %9.2f us %8.1f GB/s\n", ns, lg, us, bytes / us / 1e3);
                         fflush(stdout);
                     }
+            if (argc > 2 && !strcmp(argv[2], "flavour")) {
+                CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rounds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                for (int rep = 0; rep < 2; ++rep)
+                    for (int fl : {0, 1, 2}) {
+                        g_flavour = fl;
+                        g_xcd = 1;
+                        const char *fn = fl == 0 ? "plain" : fl == 1 ? "nt   " : "sc1  ";
+                        double us = timeit(reps, [&](int i) {
+                            const size_t sl = (size_t)i % (slots * 2);
+                            hipLaunchKernelGGL(k_fill, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, 0, buf[sl / slots] + (sl % slots) * bytes, bytes, fl);
+                        });
+                        printf("ns %d lg %2d  %s linear 4 KB fill                                   %9.2f us %8.1f GB/s\n", ns, lg, fn, us, bytes / us / 1e3);
+                        us = timeit(reps, [&](int i) {
+                            hipLaunchKernelGGL(k_rounds, dim3((unsigned)((nblk + 47) / 48)), dim3(192), (size_t)3 * 22 * 1024, 0, streams(i), nblk, 30);
+                        });
+                        printf("ns %d lg %2d  %s round-sliced, 3 waves x 16 blocks, lds 66 KB, spin 30  %9.2f us %8.1f GB/s\n", ns, lg, fn, us, bytes / us / 1e3);
+                        us = timeit(reps, [&](int i) {
+                            hipLaunchKernelGGL(k_colburst, dim3((unsigned)((nblk + 15) / 16)), dim3(64), (size_t)22 * 1024, 0, streams(i), nblk, 60);
+                        });
+                        printf("ns %d lg %2d  %s column bursts, 1 wave x 16 blocks, lds 22 KB, spin 60  %9.2f us %8.1f GB/s\n", ns, lg, fn, us, bytes / us / 1e3);
+                        for (int nb : {4, 8, 16}) {
+                            us = timeit(reps, [&](int i) {
+                                hipLaunchKernelGGL(k_unit, dim3((unsigned)((nblk + nb - 1) / nb)), dim3(64), (size_t)nb * bpb, 0, streams(i), nblk, nb, 0);
+                            });
+                            printf("ns %d lg %2d  %s one-shot nb %2d, 64 threads, lds %6zu                 %9.2f us %8.1f GB/s\n", ns, lg, fn, nb, (size_t)nb * bpb, us, bytes / us / 1e3);
+                        }
+                        fflush(stdout);
+                    }
+                g_flavour = 2;
+                g_xcd = 0;
+                continue;
+            }
             if (argc > 2 && !strcmp(argv[2], "rank")) {
                 CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rounds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 for (int rep = 0; rep < 3; ++rep) {
