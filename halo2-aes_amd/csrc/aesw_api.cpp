@@ -448,8 +448,8 @@ int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, co
     }
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
-    KeyParams kp{d_key, ctx->d_tables, ko, ctx->d_rk, 1};
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, reinterpret_cast<hipStream_t>(stream)));
+    KeyParams kp{d_key, ctx->d_tables, ko, ctx->d_rk, 1, 0, 0};
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, false, reinterpret_cast<hipStream_t>(stream)));
     // a later encrypt on ANOTHER stream (the host-pointer entry points use the context's own) waits for these round keys
     HIP_TRY(ctx, hipEventRecord(ctx->key_ready, reinterpret_cast<hipStream_t>(stream)));
     ctx->key_stream = stream;
@@ -485,8 +485,8 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (!per_block_keys && kemit) {
         // shared key: its schedule witness is one key slab
-        KeyParams kp{d_keys, ctx->d_tables, ko, nullptr, 1};
-        HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, s));
+        KeyParams kp{d_keys, ctx->d_tables, ko, nullptr, 1, 0, 0};
+        HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, false, s));
     }
     const int km = per_block_keys ? 0 : (d_keys ? 1 : 2);
     if (km == 2 && stream != ctx->key_stream) {
@@ -516,8 +516,8 @@ int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint6
         return AESW_ERR_INVALID_ARG;
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
-    KeyParams kp{d_keys, ctx->d_tables, KeyOut{d_w, d_kx, d_ky, d_kz}, d_rk, n};
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves_key(ctx, layout), ctx->key_nt, reinterpret_cast<hipStream_t>(stream)));
+    KeyParams kp{d_keys, ctx->d_tables, KeyOut{d_w, d_kx, d_ky, d_kz}, d_rk, n, 0, 0};
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves_key(ctx, layout), ctx->key_nt, ctx->xcd_remap, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 

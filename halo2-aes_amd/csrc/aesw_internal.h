@@ -33,6 +33,8 @@ struct KeyParams {
     KeyOut key;
     uint8_t *rk;  // n*176 or null
     uint64_t n;
+    uint32_t ngroups;    // filled by the launcher
+    uint32_t xcd_remap;  // 1: workgroups that share an XCD (id % 8) take one contiguous eighth of the groups
 };
 
 // key mode: 0 = per-block keys, 1 = shared key expanded in the kernel, 2 = shared key scheduled earlier (p.rk)
@@ -43,7 +45,7 @@ int flush_table_words(int layout);
 void build_flush_tables(int layout, uint32_t *out);
 // hipFuncSetAttribute(max dynamic LDS) for every instantiation, once per device: called by aesw_create()
 hipError_t warm_launch_attributes();
-hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, hipStream_t s);
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, bool xcd_remap, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
 struct AssembleParams {
     const uint8_t *x, *y, *z;        // n_blocks slabs

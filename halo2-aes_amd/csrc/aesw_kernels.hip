@@ -536,7 +536,12 @@ __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     const Tables<XT> tab{lds};
     const uint32_t stage = TAB_BYTES + wave * WAVE_LDS;
     const uint32_t rk_w = stage + St::KEY_BYTES;
-    const uint64_t blk0 = ((uint64_t)blockIdx.x * waves + wave) * BPW;
+    uint32_t grp = blockIdx.x;
+    if (a.xcd_remap) {  // as in encrypt_kernel: an XCD's workgroups write one contiguous eighth of every column
+        const uint32_t q = a.ngroups / 8, r = a.ngroups % 8, xcd = grp % 8;
+        grp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + grp / 8;
+    }
+    const uint64_t blk0 = ((uint64_t)grp * waves + wave) * BPW;
     const int64_t left = (int64_t)a.n - (int64_t)blk0;
     const int nvalid = left >= BPW ? BPW : (left > 0 ? (int)left : 0);
     if (nvalid == 0) return;
@@ -776,11 +781,14 @@ hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, 
 }
 
 template <int L, bool XT, int NT>
-static hipError_t launch_key_t(const KeyParams &p, int waves, hipStream_t stream) {
+static hipError_t launch_key_t(const KeyParams &p0, int waves, bool xr, hipStream_t stream) {
     const int bpg = waves * BPW;
-    const uint64_t groups = (p.n + bpg - 1) / bpg;
+    const uint64_t groups = (p0.n + bpg - 1) / bpg;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
+    KeyParams p = p0;
+    p.ngroups = (uint32_t)groups;
+    p.xcd_remap = xr ? 1u : 0u;
     const size_t lds = TAB_BYTES + (size_t)waves * (Stage<L>::KEY_BYTES + Stage<L>::RK_BYTES_W);
     {
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&key_kernel<L, XT, NT>), lds);
@@ -791,14 +799,14 @@ static hipError_t launch_key_t(const KeyParams &p, int waves, hipStream_t stream
 }
 
 template <int L, bool XT>
-static hipError_t launch_key_nt(const KeyParams &p, int waves, int nt, hipStream_t s) {
-    return nt == 2 ? launch_key_t<L, XT, 2>(p, waves, s) : nt == 1 ? launch_key_t<L, XT, 1>(p, waves, s) : launch_key_t<L, XT, 0>(p, waves, s);
+static hipError_t launch_key_nt(const KeyParams &p, int waves, int nt, bool xr, hipStream_t s) {
+    return nt == 2 ? launch_key_t<L, XT, 2>(p, waves, xr, s) : nt == 1 ? launch_key_t<L, XT, 1>(p, waves, xr, s) : launch_key_t<L, XT, 0>(p, waves, xr, s);
 }
 
-hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int nt, hipStream_t s) {
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int nt, bool xcd_remap, hipStream_t s) {
     if (waves < 1 || waves > 4) return hipErrorInvalidValue;
-    if (layout == DENSE) return xt ? launch_key_nt<DENSE, true>(p, waves, nt, s) : launch_key_nt<DENSE, false>(p, waves, nt, s);
-    return xt ? launch_key_nt<PACKED, true>(p, waves, nt, s) : launch_key_nt<PACKED, false>(p, waves, nt, s);
+    if (layout == DENSE) return xt ? launch_key_nt<DENSE, true>(p, waves, nt, xcd_remap, s) : launch_key_nt<DENSE, false>(p, waves, nt, xcd_remap, s);
+    return xt ? launch_key_nt<PACKED, true>(p, waves, nt, xcd_remap, s) : launch_key_nt<PACKED, false>(p, waves, nt, xcd_remap, s);
 }
 
 // Dynamic LDS above 48 KiB needs hipFuncSetAttribute once per (kernel, device).  aesw_create() does it here for every

@@ -13,10 +13,11 @@ nk = 1 << 20
 keys = torch.randint(0, 256, (nk, 16), dtype=torch.uint8, device="cuda")
 for layout, name in ((pkg.LAYOUT_PACKED, "packed"), (pkg.LAYOUT_DENSE, "dense")):
     ctxs = []
-    for w in ((1, 2), (2, 2), (3, 2), (4, 2), (4, 0), (4, 1), (2, 0), (2, 1)):  # (waves per group, store mode)
+    for w in ((4, 1, 1), (4, 1, 0), (4, 2, 1), (4, 2, 0), (2, 1, 1), (2, 1, 0), (1, 1, 1), (1, 2, 1)):  # (waves per group, store mode, xcd_remap)
         c = pkg.Context(0)
         c.set_option("waves_pbk", w[0])
         c.set_option("key_store_mode", w[1])
+        c.set_option("xcd_remap", w[2])
         ctxs.append((w, c))
     res = {w: [] for w, _ in ctxs}
     for _ in range(5):
@@ -33,4 +34,4 @@ for layout, name in ((pkg.LAYOUT_PACKED, "packed"), (pkg.LAYOUT_DENSE, "dense"))
     out = sum(pkg.key_column_stride(layout, c) for c in range(3)) + 96
     for w, _ in ctxs:
         med = statistics.median(res[w])
-        print("%-7s waves,store %s  %8.1f us  written %6.0f GB/s  algorithmic %6.0f GB/s" % (name, w, med, out * nk / med / 1e3, 952 * nk / med / 1e3))
+        print("%-7s waves,store,xcd %s  %8.1f us  written %6.0f GB/s  algorithmic %6.0f GB/s" % (name, w, med, out * nk / med / 1e3, 952 * nk / med / 1e3))
