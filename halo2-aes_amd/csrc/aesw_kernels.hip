@@ -157,10 +157,16 @@ __device__ __forceinline__ uint8_t *uniform_ptr(uint8_t *p) {
 template <class W, bool ON>
 struct ColSched {
     static constexpr int N = ON ? sched_first<W>(10) : 0;
+    static constexpr int N4 = (N + 3) / 4;  // the device table holds four instructions' descriptors per lane and 16-byte load
     uint32_t d[N > 0 ? N : 1];
-    __device__ __forceinline__ void load(const uint32_t *tab, int lane, uint32_t stage) {
+    __device__ __forceinline__ void load(const u32x4 *tab4, int lane, uint32_t stage) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) d[i] = tab[i * LANES + lane] + stage;
+        for (int g = 0; g < N4; ++g) {
+            const u32x4 v = tab4[g * LANES + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * g + j < N) d[4 * g + j] = v[j] + stage;
+        }
     }
 };
 
@@ -197,6 +203,9 @@ struct Scheds {
     ColSched<WinZ<L>, true> z;
     static constexpr int OFF_Y = ColSched<WinX<L>, Geo<L>::HAS_X>::N, OFF_Z = OFF_Y + ColSched<WinY<L>, true>::N,
                          TOTAL = OFF_Z + ColSched<WinZ<L>, true>::N;
+    // the same in the device layout (groups of four instructions, u32x4 per lane)
+    static constexpr int OFF4_Y = ColSched<WinX<L>, Geo<L>::HAS_X>::N4, OFF4_Z = OFF4_Y + ColSched<WinY<L>, true>::N4,
+                         TOTAL4 = OFF4_Z + ColSched<WinZ<L>, true>::N4;
 };
 
 template <int L, int NT, int R, bool FULL>
@@ -259,15 +268,25 @@ template <int L> __host__ __device__ constexpr int enc_wave_lds(bool kemit) {
 static_assert(TAB_BYTES + RKS_BYTES + 3 * enc_wave_lds<PACKED>(true) <= 65536, "packed windows grew: 3-wave groups no longer addressable");
 static_assert(TAB_BYTES + RKS_BYTES + 2 * enc_wave_lds<DENSE>(true) <= 65536, "dense windows grew: 2-wave groups no longer addressable");
 
-// words per layout of the flush-descriptor table the host uploads (x, then y, then z instructions, 64 lanes each)
+// words per layout of the flush-descriptor table the host uploads: per column, groups of four instructions, one u32x4 per
+// lane and group (so a lane fetches its descriptors with a quarter of the load instructions); unused tail words are 0
 int flush_table_words(int layout) {
-    return (layout == DENSE ? Scheds<DENSE>::TOTAL : layout == VALUES ? Scheds<VALUES>::TOTAL : Scheds<PACKED>::TOTAL) * LANES;
+    return (layout == DENSE ? Scheds<DENSE>::TOTAL4 : layout == VALUES ? Scheds<VALUES>::TOTAL4 : Scheds<PACKED>::TOTAL4) * LANES * 4;
+}
+template <class W>
+static void build_column_device_layout(uint32_t *out4) {
+    constexpr int N = sched_first<W>(10), N4 = (N + 3) / 4;
+    uint32_t plain[(N > 0 ? N : 1) * LANES];
+    build_flush_table<W>(plain);  // instruction-major: word i*64 + lane (what the tests and the lane model read)
+    for (int g = 0; g < N4; ++g)
+        for (int lane = 0; lane < LANES; ++lane)
+            for (int j = 0; j < 4; ++j) out4[(g * LANES + lane) * 4 + j] = 4 * g + j < N ? plain[(4 * g + j) * LANES + lane] : 0u;
 }
 template <int L>
 static void build_tables_for(uint32_t *out) {
-    if (Geo<L>::HAS_X) build_flush_table<WinX<L>>(out);
-    build_flush_table<WinY<L>>(out + Scheds<L>::OFF_Y * LANES);
-    build_flush_table<WinZ<L>>(out + Scheds<L>::OFF_Z * LANES);
+    if (Geo<L>::HAS_X) build_column_device_layout<WinX<L>>(out);
+    build_column_device_layout<WinY<L>>(out + Scheds<L>::OFF4_Y * LANES * 4);
+    build_column_device_layout<WinZ<L>>(out + Scheds<L>::OFF4_Z * LANES * 4);
 }
 void build_flush_tables(int layout, uint32_t *out) {
     if (layout == DENSE) build_tables_for<DENSE>(out);
@@ -365,9 +384,10 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     // flush descriptors: one dword per lane and store instruction, kept in registers for every group this workgroup handles
     Scheds<L> sc;
     if (NT != 3) {
-        if (G::HAS_X) sc.x.load(a.ftab, lane0, stage0 + St::OX);
-        sc.y.load(a.ftab + Scheds<L>::OFF_Y * LANES, lane0, stage0 + St::OY);
-        sc.z.load(a.ftab + Scheds<L>::OFF_Z * LANES, lane0, stage0 + St::OZ);
+        const u32x4 *ft4 = reinterpret_cast<const u32x4 *>(a.ftab);
+        if (G::HAS_X) sc.x.load(ft4, lane0, stage0 + St::OX);
+        sc.y.load(ft4 + Scheds<L>::OFF4_Y * LANES, lane0, stage0 + St::OY);
+        sc.z.load(ft4 + Scheds<L>::OFF4_Z * LANES, lane0, stage0 + St::OZ);
     }
 
     // the first group's inputs first, so their latency hides behind the table load
