@@ -61,6 +61,12 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--c3-log2-blocks", type=int, default=None, help="N>1 extra: blocks per GPU of the configs[3] run (default 21)")
     ap.add_argument("--c4-log2-blocks", type=int, default=24, help="N=1 extra: blocks of the configs[4] streaming run")
+    ap.add_argument("--c4-rank-log2-blocks", type=int, default=21,
+                    help="N>1: blocks EVERY rank streams to its own host in the configs[4] leg (2^24 over 8 GPUs = 2^21 per GPU)")
+    ap.add_argument("--arena", choices=["auto", "on", "off"], default="auto",
+                    help="output columns of a set in ONE device allocation (aesw_columns_alloc) instead of separate tensors")
+    ap.add_argument("--gather-path", choices=["auto", "torch"], default="auto",
+                    help="N>1: 'torch' forces the torch.distributed point-to-point gather instead of the C ABI's RCCL gather")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of a hipGraph")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to aesw_set_option")
@@ -72,8 +78,9 @@ class Runner:
     """One workload: inputs resident in HBM, a ring of output buffer sets larger
     than the 256 MiB Infinity Cache so consecutive steps do not rewrite cached lines."""
 
-    def __init__(self, pkg, ctx, torch, n, per_block_keys, layout, key_slab, seed):
+    def __init__(self, pkg, ctx, torch, n, per_block_keys, layout, key_slab, seed, arena=False):
         self.pkg, self.ctx, self.torch, self.n = pkg, ctx, torch, n
+        self.arena = arena
         self.pbk, self.layout, self.key_slab = per_block_keys, layout, key_slab
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g).cuda()
@@ -87,7 +94,9 @@ class Runner:
             per_set += (96 + sum(pkg.key_column_stride(layout, c) for c in range(3))) * n
         self.out_bytes_per_step = per_set
         self.nsets = max(2, min(8, -(-(640 << 20) // per_set)))
-        self.sets = [ctx.alloc_witness(n, layout, want_ct=False, key_slab=key_slab, n_keys=n) for _ in range(self.nsets)]
+        # arena: one device allocation per set with aligned column bases (aesw_columns_alloc); else one tensor per column
+        self.sets = [(ctx.alloc_columns(n, layout, key_slab=key_slab) if arena else
+                      ctx.alloc_witness(n, layout, want_ct=False, key_slab=key_slab, n_keys=n)) for _ in range(self.nsets)]
         self.lib = pkg.load_library()
         self.h = ctx._h
         self._ks = [pkg.api.KeySlab(*[t.data_ptr() for t in s.key[:4]]) if key_slab else None for s in self.sets]
@@ -96,6 +105,13 @@ class Runner:
             self.bytes_per_block = BYTES_VALUES + (936 + 16 if (per_block_keys and key_slab) else 0)
         self.graph = None
         self.graph_steps = 0
+
+    def close(self):
+        """Release the arenas (separate tensors go back to torch's allocator by themselves)."""
+        if self.arena:
+            for w in self.sets:
+                self.ctx.free_columns(w)
+        self.sets, self._ks, self.graph = [], [], None
 
     def launch(self, i, stream):
         s = self.sets[i % self.nsets]
@@ -119,6 +135,11 @@ class Runner:
             try:
                 cap = torch.cuda.Stream()
                 cap.wait_stream(stream)
+                if not self.pbk:
+                    # a scheduled-key launch can only be captured on the stream its key was scheduled on (aesw.h)
+                    with torch.cuda.stream(cap):
+                        self.ctx.schedule_key(self.keys, layout=self.layout, key_slab=False)
+                    cap.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=cap):
                     csp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -165,36 +186,107 @@ class Runner:
 
 def cpu_baseline(per_block_keys, n_target_seconds=12.0):
     """The CPU oracle on this host's cores: 1 thread (the reference synthesizes
-    single-threaded) on a bounded sample of the headline workload's shape."""
+    single-threaded) on a bounded sample of the headline workload's shape.  Output arrays are
+    allocated and touched BEFORE the clock starts: the timed region is the oracle's work only."""
     import numpy as np
     import oracle_lib
+    from oracle_lib import _p
     orc = oracle_lib.Oracle()
     rng = np.random.default_rng(SEED + 2)
+    sx, sy, sz = oracle_lib.ENC_STRIDE[oracle_lib.PACKED]
+    kxs, kys, kzs = oracle_lib.KEY_STRIDE[oracle_lib.PACKED]
 
-    def once(pt, keys, threads):
+    def buffers(n):
+        sizes = [n * sx, n * sy, n * sz, n * 16]
+        if per_block_keys:
+            sizes += [n * oracle_lib.WORDS_ROWS, n * kxs, n * kys, n * kzs, n * 176]
+        bufs = [np.empty(b, np.uint8) for b in sizes]
+        for b in bufs:
+            b.fill(1)  # first touch: page faults happen here, not inside the timed region
+        return bufs
+
+    def once(pt, keys, threads, bufs):
+        n = pt.shape[0]
         t0 = time.perf_counter()
-        orc.encrypt_witness(pt, keys, layout=oracle_lib.PACKED, threads=threads)
-        if per_block_keys:  # the key-schedule witness of every block's key (src/key_schedule.rs:80-224)
-            orc.key_schedule_witness(keys, layout=oracle_lib.PACKED, threads=threads)
-        return time.perf_counter() - t0
+        rc = orc.L.aesw_o_encrypt_witness(C.byref(orc.t), _p(pt), _p(keys), 1 if per_block_keys else 0, n, oracle_lib.PACKED,
+                                          _p(bufs[0]), _p(bufs[1]), _p(bufs[2]), _p(bufs[3]), threads)
+        if per_block_keys and not rc:  # the key-schedule witness of every block's key (src/key_schedule.rs:80-224)
+            rc = orc.L.aesw_o_key_schedule_witness(C.byref(orc.t), _p(keys), n, oracle_lib.PACKED, _p(bufs[4]), _p(bufs[5]),
+                                                   _p(bufs[6]), _p(bufs[7]), _p(bufs[8]), threads)
+        dt = time.perf_counter() - t0
+        if rc:
+            raise RuntimeError("oracle rc=%d" % rc)
+        return dt
 
     def inputs(n):
         return (rng.integers(0, 256, (n, 16), dtype=np.uint8),
                 rng.integers(0, 256, (n, 16) if per_block_keys else 16, dtype=np.uint8))
 
     probe = 2048
-    rate = probe / once(*inputs(probe), 1)
+    rate = probe / once(*inputs(probe), 1, buffers(probe))
     n = int(max(4096, min(1 << 20, rate * n_target_seconds)))
     pt, keys = inputs(n)
-    dt1 = once(pt, keys, 1)
+    bufs = buffers(n)
+    dt1 = once(pt, keys, 1, bufs)
     cores = os.cpu_count() or 1
-    dtn = once(pt, keys, cores)
+    threads = min(cores, 256)  # the oracle's thread pool is capped at 256 (oracle/aesw_oracle.c)
+    # a larger sample for the all-core leg, or thread start-up dominates it
+    n_all = int(min(1 << 20, max(n, n * threads // 8)))
+    pt_a, keys_a = inputs(n_all)
+    bufs_a = buffers(n_all)
+    once(pt_a[:4096], keys_a[:4096] if per_block_keys else keys_a, threads, bufs_a)  # one small call first (code and tables warm)
+    dtn = once(pt_a, keys_a, threads, bufs_a)
     return {
         "value": n / dt1, "unit": "blocks/s", "cores": 1, "kind": "port",
-        "sample": "%d blocks, %s, packed layout, oracle/aesw_oracle.c single thread (%.1f s)" % (
+        "sample": "%d blocks, %s, packed layout, oracle/aesw_oracle.c single thread (%.1f s), outputs pre-allocated and touched" % (
             n, "per-block keys + key-schedule witness" if per_block_keys else "shared key", dt1),
-        "all_cores": {"value": n / dtn, "cores": cores},
+        "all_cores": {"value": n_all / dtn, "cores": cores, "threads": threads,
+                      "sample": "%d blocks in %.2f s" % (n_all, dtn)},
     }
+
+
+def c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=True, samples=6):
+    """BASELINE configs[4] on this rank's GPU: aesw_encrypt_witness_stream over pt4 with a CHEAP consumer -- the
+    pt ^ rk0 check on every chunk (what a host's assign loop would at least have to touch) plus a copy of the first
+    256 blocks of `samples` chunks.  The oracle comparison of those copies happens AFTER the stream has ended and
+    outside every reported time (it is the checker's time, not a host-assign time).
+    Consumer to match in the reference: region.assign_advice of src/aes128.rs:176-192, benches/aes128.rs:44-56."""
+    import numpy as np
+    n4 = pt4.shape[0]
+    strides = [pkg.column_stride(lay, c) for c in range(3)]
+    chunk = ctx.get_option("chunk_blocks")
+    sampled = set(int(v) for v in np.linspace(0, -(-n4 // chunk) - 1, samples).astype(int))
+    bad = [0]
+    kept = []
+
+    def consume(first, count, x, y, z):
+        p = pt4[first:first + count]
+        if not np.array_equal(z.reshape(count, strides[2])[:, :16], p ^ key4):
+            bad[0] += 1
+        if first // chunk in sampled:
+            m = min(count, 256)
+            kept.append((first, m, [np.array(c[:m * s_]) if s_ else None for c, s_ in ((x, strides[0]), (y, strides[1]), (z, strides[2]))]))
+        return 0
+
+    ctx.encrypt_witness_stream(pt4[:min(n4, 1 << 16)], None, lambda *args: 0, layout=lay)  # sizes the context's buffers
+    t0 = time.perf_counter()
+    ctx.encrypt_witness_stream(pt4, None, consume, layout=lay)
+    dt = time.perf_counter() - t0
+    st = ctx.last_stream_stats()
+    per = sum(strides)
+    if verify:
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        for first, m, cols in kept:
+            e = orc.encrypt_witness(pt4[first:first + m], key4, layout=olay)
+            for got, exp in zip(cols, (e.x, e.y, e.z)):
+                if got is not None and not np.array_equal(got, exp):
+                    bad[0] += 1
+    return {"blocks": n4, "blocks_per_s": n4 / dt, "seconds": dt, "GBps_to_host": n4 * per / dt / 1e9,
+            "kernel_s": st["kernel_ns"] * 1e-9, "kernel_blocks_per_s": n4 / (st["kernel_ns"] * 1e-9),
+            "d2h_s": st["d2h_ns"] * 1e-9, "d2h_GBps": st["bytes_to_host"] / (st["d2h_ns"] * 1e-9) / 1e9,
+            "consumer_s": st["consumer_ns"] * 1e-9, "wait_s": st["wait_ns"] * 1e-9, "chunks": st["chunks"],
+            "sampled_chunks_verified_after_the_stream": len(kept) if verify else 0, "mismatches": bad[0]}
 
 
 class Watchdog:
@@ -275,7 +367,8 @@ def main():
     lg = a.log2_blocks or (20 if pbk else 16)
     n = 1 << lg
     # the per-rank workload at N>1 IS the N=1 headline workload, so the driver's 1/2/4/8 curve compares like with like
-    runner = Runner(pkg, ctx, torch, n, pbk, layout, pbk, SEED + (2 if pbk else 1) + rank)
+    use_arena = a.arena == "on"  # "auto": separate tensors until the A/B of profiles/r03_study/arena_ab.md says otherwise
+    runner = Runner(pkg, ctx, torch, n, pbk, layout, pbk, SEED + (2 if pbk else 1) + rank, arena=use_arena)
     wl = ("2^%d blocks, per-block keys (+ key-schedule witness), %s advice columns (BASELINE configs[2])" if pbk else
           "2^%d blocks, one shared key, %s advice columns (BASELINE configs[1])") % (lg, a.layout)
     runner.prepare(a.steps, a.warmup, not a.no_graph)
@@ -310,7 +403,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl, "blocks_per_gpu": n, "layout": a.layout, "sharding": "blocks by rank, no collective",
                    "launch": "hipGraph of %d launches" % a.steps if graphed else "host launches",
-                   "output_ring_sets": runner.nsets},
+                   "output_ring_sets": runner.nsets, "columns": "one arena per set (aesw_columns_alloc)" if use_arena else "one tensor per column"},
         "timing": {"replays": len(replays), "reported": "median replay (exactly %d steps)" % a.steps,
                    "ms_per_step_wall": [w * 1e3 / a.steps for w, _ in replays],
                    "ms_per_step_events": [m for _, m in replays],
@@ -334,6 +427,7 @@ def main():
     extras = {}
     if rank == 0 and dist is None and not a.no_extras:
         import numpy as np
+        runner.close()
         del runner
         torch.cuda.empty_cache()
         # every host-path extra schedules its own key (the headline runner has per-block keys: nothing scheduled yet)
@@ -391,44 +485,17 @@ def main():
             extras["pcie_inclusive"] = res
         except Exception as e:
             extras["pcie_inclusive"] = {"error": str(e)}
-        try:  # BASELINE configs[4] on one GPU: 2^24 blocks streamed to a verifying consumer, the parts timed separately
+        try:  # BASELINE configs[4] on one GPU: 2^24 blocks streamed to a checking consumer, the parts timed separately
             import oracle_lib
-            orc = oracle_lib.Oracle()
             n4 = 1 << a.c4_log2_blocks
             pt4 = np.random.default_rng(SEED + 4).integers(0, 256, (n4, 16), dtype=np.uint8)
             key4 = hkey.cpu().numpy()
             c4 = {"blocks": n4, "note": "aesw_encrypt_witness_stream, scheduled key: chunk i+1's kernel and D2H overlap the consumer of chunk i; "
                                         "kernel_s / d2h_s are device time summed over chunks (HIP events), consumer_s / wait_s host time; "
-                                        "the consumer checks pt ^ rk0 on every chunk and compares 6 sampled chunks x 256 blocks with the oracle"}
+                                        "the consumer checks pt ^ rk0 on every chunk and keeps 256 blocks of 6 sampled chunks, which are "
+                                        "compared with the oracle after the stream has ended (outside every reported time)"}
             for name, lay, olay in (("values", pkg.LAYOUT_VALUES, oracle_lib.VALUES), ("packed", pkg.LAYOUT_PACKED, oracle_lib.PACKED)):
-                strides = [pkg.column_stride(lay, c) for c in range(3)]
-                chunk = ctx.get_option("chunk_blocks")
-                sampled = set(int(v) for v in np.linspace(0, -(-n4 // chunk) - 1, 6).astype(int))
-                bad = [0]
-
-                def consume(first, count, x, y, z):
-                    p = pt4[first:first + count]
-                    if not np.array_equal(z.reshape(count, strides[2])[:, :16], p ^ key4):
-                        bad[0] += 1
-                    if first // chunk in sampled:
-                        m = min(count, 256)
-                        e = orc.encrypt_witness(p[:m], key4, layout=olay)
-                        for got, exp, s in ((x, e.x, strides[0]), (y, e.y, strides[1]), (z, e.z, strides[2])):
-                            if s and not np.array_equal(got[:m * s], exp):
-                                bad[0] += 1
-                    return 0
-
-                ctx.encrypt_witness_stream(pt4[:1 << 16], None, lambda *args: 0, layout=lay)  # sizes the context's buffers
-                t0 = time.perf_counter()
-                ctx.encrypt_witness_stream(pt4, None, consume, layout=lay)
-                dt = time.perf_counter() - t0
-                st = ctx.last_stream_stats()
-                per = sum(strides)
-                c4[name] = {"blocks_per_s": n4 / dt, "seconds": dt, "GBps_to_host": n4 * per / dt / 1e9,
-                            "kernel_s": st["kernel_ns"] * 1e-9, "kernel_blocks_per_s": n4 / (st["kernel_ns"] * 1e-9),
-                            "d2h_s": st["d2h_ns"] * 1e-9, "d2h_GBps": st["bytes_to_host"] / (st["d2h_ns"] * 1e-9) / 1e9,
-                            "consumer_s": st["consumer_ns"] * 1e-9, "wait_s": st["wait_ns"] * 1e-9, "chunks": st["chunks"],
-                            "mismatches": bad[0]}
+                c4[name] = c4_stream(pkg, ctx, pt4, key4, lay, olay)
             del pt4
             extras["c4"] = c4
         except Exception as e:
@@ -470,17 +537,7 @@ def main():
                         "(one 32 MiB memcpy per column instead of 2^20 assign_advice calls); compare host_synthesize"}
             del apt, wit, sink
         except Exception as e:
-            # and without the consumer's copy: DMA straight into the host's (page-locked) advice buffer
-            whole = pkg.api.host_alloc(16 * (32 << k))
-            ctx.assemble_advice_host(k, n_sets, wit, kw, nn, whole, layout=pkg.LAYOUT_PACKED, as_fr=True)
-            t0 = time.perf_counter()
-            ctx.assemble_advice_host(k, n_sets, wit, kw, nn, whole, layout=pkg.LAYOUT_PACKED, as_fr=True)
-            dt_direct = time.perf_counter() - t0
-            pkg.api.host_free(whole)
-            del whole
-            extras["fr_columns_to_host"] = {
-                "direct_pinned": {"seconds": dt_direct, "blocks_per_s": nn / dt_direct, "GBps_to_host": 16 * (32 << k) / dt_direct / 1e9,
-                                  "note": "aesw_assemble_advice_host into one page-locked buffer (aesw_host_alloc / aesw_host_register): no consumer copy"},"error": str(e)}
+            extras["fr_columns_to_host"] = {"error": str(e)}
         for name, nn, xpbk, lay in (("c1_packed", 1 << 16, False, pkg.LAYOUT_PACKED),
                                     ("c1_packed_2p20", 1 << 20, False, pkg.LAYOUT_PACKED),
                                     ("c1_values", 1 << 16, False, pkg.LAYOUT_VALUES),
@@ -568,13 +625,15 @@ def main():
         # through the C ABI's RCCL gather.  A per-phase watchdog reports a stalled exchange and exits NON-ZERO.
         dog = Watchdog(rank, line)
         strides = [pkg.column_stride(layout, c) for c in range(3)]
+        failed = []  # phases of the N>1 tail that raised on THIS rank: the process then exits non-zero (after printing)
 
         def timed_gather(wset, nblk):
             gcols = [wset.x, wset.y, wset.z] if a.backend == "nccl" else [c.cpu() for c in (wset.x, wset.y, wset.z)]
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
-            full = pkg.sharding.gather_columns(gcols, [nblk] * world, strides, dst=0, ctx=ctx if a.backend == "nccl" else None)
+            full = pkg.sharding.gather_columns(gcols, [nblk] * world, strides, dst=0, ctx=ctx if a.backend == "nccl" else None,
+                                               force_torch=a.gather_path == "torch")
             torch.cuda.synchronize()
             dist.barrier()
             dt = time.perf_counter() - t0
@@ -593,11 +652,13 @@ def main():
                                   "note": "per-rank column ranges gathered on rank 0, outside `value`"}
         except Exception as e:
             dog.disarm()
+            failed.append("gather")
             if rank == 0:
                 line["gather"] = {"error": str(e)}
         if not a.no_extras:
             # BASELINE configs[3]: 2^24 blocks over 8 GPUs = 2^21 per GPU, columns gathered on GPU 0 (never `value`)
             try:
+                runner.close()
                 del runner
                 torch.cuda.empty_cache()
                 n3 = 1 << (a.c3_log2_blocks or 21)
@@ -621,15 +682,77 @@ def main():
                 del r3
             except Exception as e:
                 dog.disarm()
+                failed.append("c3")
                 if rank == 0:
                     line["c3"] = {"error": str(e)}
+            # BASELINE configs[4] at N > 1: every rank streams its own shard to its own host over its own PCIe link (DESIGN 7:
+            # the right delivery path -- no gather), kernel + async D2H overlapped with a cheap consumer; ranks timed between
+            # barriers, MAX over ranks.  Consumer to match: region.assign_advice, src/aes128.rs:176-192.
+            try:
+                import numpy as np
+                import oracle_lib
+                torch.cuda.empty_cache()
+                n4 = 1 << a.c4_rank_log2_blocks
+                dog.arm("c4 set-up", 180.0)
+                hkey4 = torch.from_numpy(np.random.default_rng(SEED + 5).integers(0, 256, 16, dtype=np.uint8)).cuda()
+                ctx.schedule_key(hkey4, layout=pkg.LAYOUT_PACKED, key_slab=False)
+                torch.cuda.synchronize()
+                pt4 = np.random.default_rng(SEED + 40 + rank).integers(0, 256, (n4, 16), dtype=np.uint8)
+                key4 = hkey4.cpu().numpy()
+                ctx.encrypt_witness_stream(pt4[:1 << 16], None, lambda *args: 0, layout=pkg.LAYOUT_PACKED)  # buffers sized, untimed
+                c4n = {}
+                for name, lay, olay in (("packed", pkg.LAYOUT_PACKED, oracle_lib.PACKED), ("values", pkg.LAYOUT_VALUES, oracle_lib.VALUES)):
+                    dog.arm("c4 streaming (%s)" % name, 300.0)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    r4 = c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=False)
+                    torch.cuda.synchronize()
+                    t_rank = time.perf_counter() - t0
+                    dist.barrier()
+                    dev4 = "cuda" if a.backend == "nccl" else "cpu"
+                    tmax = torch.tensor([t_rank, r4["kernel_s"], r4["d2h_s"], r4["consumer_s"], r4["wait_s"]], dtype=torch.float64, device=dev4)
+                    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                    tsum = torch.tensor([float(r4["mismatches"]), r4["d2h_GBps"]], dtype=torch.float64, device=dev4)
+                    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                    per = sum(pkg.column_stride(lay, c) for c in range(3))
+                    c4n[name] = {"blocks_per_rank": n4, "blocks_total": n4 * world, "seconds_max_over_ranks": float(tmax[0]),
+                                 "blocks_per_s_to_hosts": n4 * world / float(tmax[0]),
+                                 "GBps_to_hosts_all_ranks": n4 * world * per / float(tmax[0]) / 1e9,
+                                 "d2h_GBps_per_rank_mean": float(tsum[1]) / world,
+                                 "kernel_s_max": float(tmax[1]), "d2h_s_max": float(tmax[2]), "consumer_s_max": float(tmax[3]),
+                                 "wait_s_max": float(tmax[4]), "mismatches": int(tsum[0]),
+                                 "rank0": {k: r4[k] for k in ("seconds", "kernel_s", "d2h_s", "d2h_GBps", "consumer_s", "wait_s", "chunks")}}
+                dog.disarm()
+                if rank == 0:
+                    c4n["note"] = ("every rank: aesw_encrypt_witness_stream over its own 2^%d-block shard into its own page-locked buffers "
+                                   "(scheduled key); the consumer checks pt ^ rk0 on every chunk (no oracle inside the timed part); time = "
+                                   "barrier .. stream end, MAX over ranks" % a.c4_rank_log2_blocks)
+                    line["c4"] = c4n
+                del pt4
+            except Exception as e:
+                dog.disarm()
+                failed.append("c4")
+                if rank == 0:
+                    line["c4"] = {"error": str(e)}
         dog.arm("shutdown", 60.0)
         try:
+            # a phase that raised on ANY rank fails the whole job: agree on it before leaving
+            ft = torch.tensor([float(len(failed))], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+            any_failed = float(ft[0]) > 0
             dist.barrier()
             dist.destroy_process_group()
         except Exception:
-            pass
+            any_failed = True
         dog.disarm()
+        if rank == 0:
+            if any_failed:
+                line["error"] = "N>1 tail failed: %s" % (", ".join(failed) or "on another rank")
+            print(json.dumps(line), flush=True)
+        if any_failed:
+            sys.exit(4)
+        return
     if rank == 0:
         print(json.dumps(line))
 

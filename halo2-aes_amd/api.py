@@ -47,6 +47,19 @@ class KeySlab(C.Structure):
     _fields_ = [("w", C.c_void_p), ("kx", C.c_void_p), ("ky", C.c_void_p), ("kz", C.c_void_p)]
 
 
+class Columns(C.Structure):
+    """aesw_columns: one device allocation holding every output column of a batch (aesw_columns_alloc)."""
+    _fields_ = [("base", C.c_void_p), ("bytes", C.c_uint64), ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p),
+                ("ct", C.c_void_p), ("key", KeySlab)]
+
+
+class _DevView:
+    """A raw device range as a __cuda_array_interface__ object, so torch can wrap it without owning it."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
 # every symbol include/aesw.h declares: (restype, argtypes)
 _P, _I, _U64, _U32, _I64 = C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_int64
 SYMBOLS = {
@@ -75,6 +88,8 @@ SYMBOLS = {
     "aesw_lookup_table_device": (_I, [_P, _P, _P, _P, _P, _P]),
     "aesw_expand_fr_device": (_I, [_P, _P, _U64, _P, _P]),
     "aesw_assemble_advice_device": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
+    "aesw_columns_alloc": (_I, [_P, _U64, _I, _I, _I, C.POINTER(Columns)]),
+    "aesw_columns_free": (_I, [_P, C.POINTER(Columns)]),
     "aesw_encrypt_witness": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab)]),
     "aesw_key_schedule_witness": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P]),
     "aesw_encrypt_witness_stream": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P]),
@@ -333,10 +348,14 @@ class Context:
             self._h = C.c_void_p()
             raise AeswError(rc, "aesw_create(device=%d)" % device)
         self.device = device
+        self._arenas = {}  # y pointer -> Columns of alloc_columns()
 
     # -- lifetime
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            for cols in list(getattr(self, "_arenas", {}).values()):
+                self._lib.aesw_columns_free(self._h, C.byref(cols))
+            self._arenas = {}
             self._lib.aesw_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -401,6 +420,38 @@ class Context:
                              *[torch.empty(m * key_column_stride(layout, c), dtype=torch.uint8, device=dev)
                                for c in range(3)], None)
         return Witness(cols[0], cols[1], cols[2], ct, key)
+
+    def alloc_columns(self, n: int, layout: int = K.LAYOUT_PACKED, want_ct: bool = False, key_slab: bool = False):
+        """alloc_witness through the C ABI's arena (aesw_columns_alloc): ONE device allocation, every column on an
+        aligned boundary (option "arena_align_log2"; auto = 1 GiB for large batches).  The returned Witness's tensors
+        are views of that allocation, which lives until free_columns(witness) or the Context is closed."""
+        torch = self._torch()
+        cols = Columns()
+        self._check(self._lib.aesw_columns_alloc(self._h, n, layout, 1 if key_slab else 0, 1 if want_ct else 0, C.byref(cols)),
+                    "aesw_columns_alloc")
+        dev = self._dev()
+
+        def view(ptr, nbytes):
+            if not ptr or not nbytes:
+                return torch.empty(0, dtype=torch.uint8, device=dev)
+            return torch.as_tensor(_DevView(ptr, nbytes), device=dev)
+
+        x, y, z = (view(getattr(cols, c), n * column_stride(layout, i)) for i, c in enumerate("xyz"))
+        ct = view(cols.ct, n * 16).view(n, 16) if want_ct else None
+        key = None
+        if key_slab:
+            key = KeyWitness(view(cols.key.w, n * K.WORDS_ROWS), *[view(getattr(cols.key, c), n * key_column_stride(layout, i))
+                                                                   for i, c in enumerate(("kx", "ky", "kz"))], None)
+        wit = Witness(x, y, z, ct, key)
+        self._arenas[y.data_ptr()] = cols  # every layout has a y column
+        return wit
+
+    def free_columns(self, wit) -> None:
+        """Release the arena behind a Witness from alloc_columns (its tensors must not be used afterwards)."""
+        cols = self._arenas.pop(wit.y.data_ptr(), None)
+        if cols is None:
+            raise ValueError("not a witness of alloc_columns (or already freed)")
+        self._check(self._lib.aesw_columns_free(self._h, C.byref(cols)), "aesw_columns_free")
 
     # -- device entry points
     def schedule_key(self, key, layout: int = K.LAYOUT_PACKED, key_slab: bool = True):

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -38,6 +39,7 @@ struct aesw_ctx {
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
     bool xcd_remap = true;  // workgroups that share an XCD take one contiguous eighth of the block groups: +3-4 % at 2^20 blocks (tools/sweep.py xcd)
     int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
+    int arena_align_log2 = 0;  // aesw_columns_alloc: column alignment (0 = auto: 1 GiB for large batches, else 2 MiB)
 #ifdef AESW_TRACE
     uint64_t *trace = nullptr;
 #endif
@@ -199,9 +201,17 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
         for (int r = 0; r < KEY_ROWS; ++r) pidx[3 * AES_ROWS + c * KEY_ROWS + r] = (int16_t)kk[r];
     }
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_pidx), pidx.size() * sizeof(int16_t)), "hipMalloc(pidx)");
+    // the flush schedules depend on the layout only: searched once per process (~20 ms each), uploaded per context
+    static std::vector<uint32_t> host_ftab[3];
+    static std::once_flag ftab_once;
+    std::call_once(ftab_once, [] {
+        for (int l = 0; l < 3; ++l) {
+            host_ftab[l].resize((size_t)flush_table_words(l));
+            build_flush_tables(l, host_ftab[l].data());
+        }
+    });
     for (int l = 0; l < 3 && rc == AESW_OK; ++l) {
-        std::vector<uint32_t> ft((size_t)flush_table_words(l));
-        build_flush_tables(l, ft.data());
+        const std::vector<uint32_t> &ft = host_ftab[l];
         T(hipMalloc(reinterpret_cast<void **>(&ctx->d_ftab[l]), ft.size() * sizeof(uint32_t)), "hipMalloc(flush table)");
         if (rc == AESW_OK) T(hipMemcpy(ctx->d_ftab[l], ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(flush table)");
     }
@@ -397,6 +407,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { ctx->xcd_remap = value != 0; return AESW_OK; }
     if (!std::strcmp(name, "lds_pad")) { if (value < 0 || value > 120 * 1024) return AESW_ERR_INVALID_ARG; ctx->lds_pad = value; return AESW_OK; }
+    if (!std::strcmp(name, "arena_align_log2")) { if (value != 0 && (value < 7 || value > 32)) return AESW_ERR_INVALID_ARG; ctx->arena_align_log2 = (int)value; return AESW_OK; }
 #ifdef AESW_TRACE
     if (!std::strcmp(name, "trace_ptr")) { ctx->trace = reinterpret_cast<uint64_t *>(value); return AESW_OK; }
 #endif
@@ -405,14 +416,27 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     return AESW_ERR_INVALID_ARG;
 }
 
+static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk);
+static int auto_waves_key(const aesw_ctx *ctx, int layout);
+
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!ctx || !name || !value) return AESW_ERR_INVALID_ARG;
     if (!std::strcmp(name, "waves_shared")) { *value = ctx->waves_shared; return AESW_OK; }
     if (!std::strcmp(name, "waves_pbk")) { *value = ctx->waves_pbk; return AESW_OK; }
+    // what a launch really uses (0 = auto resolved, values above the layout's maximum clamped): packed layout
+    if (!std::strcmp(name, "effective_waves_shared")) { *value = auto_waves(ctx, AESW_LAYOUT_PACKED, false); return AESW_OK; }
+    if (!std::strcmp(name, "effective_waves_pbk")) { *value = auto_waves(ctx, AESW_LAYOUT_PACKED, true); return AESW_OK; }
+    if (!std::strcmp(name, "effective_waves_key")) { *value = auto_waves_key(ctx, AESW_LAYOUT_PACKED); return AESW_OK; }
     if (!std::strcmp(name, "nt_stores")) { *value = ctx->nt == 1; return AESW_OK; }
     if (!std::strcmp(name, "store_mode")) { *value = ctx->nt; return AESW_OK; }
+    if (!std::strcmp(name, "key_store_mode")) { *value = ctx->key_nt; return AESW_OK; }
+    if (!std::strcmp(name, "fr_store_mode")) { *value = ctx->fr_nt; return AESW_OK; }
+    if (!std::strcmp(name, "fr_geometry")) { *value = ctx->fr_geo; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { *value = ctx->grid_cap; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { *value = ctx->xcd_remap; return AESW_OK; }
+    if (!std::strcmp(name, "lds_pad")) { *value = ctx->lds_pad; return AESW_OK; }
+    if (!std::strcmp(name, "arena_align_log2")) { *value = ctx->arena_align_log2; return AESW_OK; }
+    if (!std::strcmp(name, "force_table_path")) { *value = ctx->xt ? 0 : 1; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { *value = ctx->chunk_blocks; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
 }
@@ -494,7 +518,13 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
         // captured the wait would pull the key stream into the capture; capture on the stream the key was scheduled on.
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-        if (cs == hipStreamCaptureStatusNone) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->key_ready, 0));
+        if (cs != hipStreamCaptureStatusNone) {
+            // a captured launch that reads the scheduled round keys with no dependency on the launch that writes them
+            // would race on replay: refuse instead of dropping the wait silently
+            ctx->last_error = "scheduled-key encrypt captured on a stream other than the one aesw_schedule_key_device ran on";
+            return AESW_ERR_INVALID_ARG;
+        }
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->key_ready, 0));
     }
     EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, ctx->d_ftab[layout], d_x, d_y, d_z, d_ct,
                 per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n, 0, 0};
@@ -580,6 +610,55 @@ int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cell
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     HIP_TRY(ctx, launch_expand_fr(d_cells, n_cells, ctx->d_fr_lut, d_fr, ctx->fr_nt, ctx->fr_geo, reinterpret_cast<hipStream_t>(stream)));
+    return AESW_OK;
+}
+
+// ---- one allocation for every output column of a batch -----------------------------
+
+int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab, int with_ct, aesw_columns *out) {
+    if (!ctx || !out || !valid_layout(layout) || n == 0 || n > ((uint64_t)1 << 40)) return AESW_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    const uint64_t sx = aesw_column_stride(layout, 0), sy = aesw_column_stride(layout, 1), sz = aesw_column_stride(layout, 2);
+    uint64_t align;
+    if (ctx->arena_align_log2) {
+        align = (uint64_t)1 << ctx->arena_align_log2;
+    } else {
+        const uint64_t smallest = n * (sz < sy ? sz : sy);  // z is the smallest encrypt column in every layout
+        align = smallest >= ((uint64_t)64 << 20) ? ((uint64_t)1 << 30) : ((uint64_t)2 << 20);
+    }
+    // sizes in the order the columns are laid out; a column of size 0 takes no room
+    const uint64_t size[8] = {n * sx, n * sy, n * sz, with_ct ? n * 16 : 0,
+                              with_key_slab ? n * WORDS_ROWS : 0, with_key_slab ? n * aesw_key_column_stride(layout, 0) : 0,
+                              with_key_slab ? n * aesw_key_column_stride(layout, 1) : 0, with_key_slab ? n * aesw_key_column_stride(layout, 2) : 0};
+    uint64_t off[8], end = 0;
+    for (int i = 0; i < 8; ++i) {
+        end = (end + align - 1) / align * align;
+        off[i] = end;
+        end += size[i];
+    }
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    // hipMalloc returns memory aligned to the allocation granule only: over-allocate by one alignment unit
+    uint8_t *raw = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&raw), end + align));
+    const uint64_t lead = (align - reinterpret_cast<uintptr_t>(raw) % align) % align;
+    uint8_t *b = raw + lead;
+    out->base = raw;
+    out->bytes = end + align;
+    auto at = [&](int i) -> uint8_t * { return size[i] ? b + off[i] : nullptr; };
+    out->x = at(0); out->y = at(1); out->z = at(2); out->ct = at(3);
+    out->key.w = at(4); out->key.kx = at(5); out->key.ky = at(6); out->key.kz = at(7);
+    return AESW_OK;
+}
+
+int aesw_columns_free(aesw_ctx *ctx, aesw_columns *cols) {
+    if (!ctx || !cols) return AESW_ERR_INVALID_ARG;
+    if (cols->base) {
+        DeviceGuard g(ctx->device);
+        if (!g.ok) return AESW_ERR_NO_DEVICE;
+        HIP_TRY(ctx, hipFree(cols->base));
+    }
+    std::memset(cols, 0, sizeof *cols);
     return AESW_OK;
 }
 
@@ -1032,8 +1111,8 @@ int aesw_assemble_advice_host(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
         HIP_TRY(ctx, hipMemcpyAsync(direct ? out + (size_t)col * col_bytes : ctx->bounce[s], q.out, col_bytes, hipMemcpyDeviceToHost, ctx->s_copy));
         HIP_TRY(ctx, hipEventRecord(copied[s], ctx->s_copy));
-        // the next launch into this device slot must not overtake the copy out of it
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_compute, copied[s], 0));
+        // no stream wait on copied[s] here: the next launch goes into the OTHER slot and may run while this column travels;
+        // this slot is written again only after drain(s) has host-synchronised copied[s]
         busy[s] = true;
         held[s] = col;
     }

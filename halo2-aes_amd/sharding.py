@@ -27,6 +27,7 @@ def shard_sizes(n: int, world: int) -> List[int]:
 
 
 _comms = {}  # (id of ctx, group) -> api.Comm
+_agreed_max = {}  # (id of ctx, group, requested bytes) -> the group-wide minimum (all ranks must cut messages alike)
 last_gather_path = None  # "aesw_gather_columns_device (RCCL)" or "torch.distributed point-to-point": what the last call used
 
 
@@ -52,7 +53,7 @@ def _aesw_comm(ctx, group):
 
 
 def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[int], dst: int = 0, group=None,
-                   max_message_bytes: int = 1 << 30, ctx=None):
+                   max_message_bytes: int = 1 << 30, ctx=None, force_torch: bool = False):
     """Gather per-rank column slices on group rank `dst`.
 
     columns: this rank's column tensors (uint8, flat, counts[rank]*stride bytes).
@@ -64,8 +65,12 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
     stream, so it is ordered behind the kernels that produced the columns without a host synchronisation; a host
     without torch calls the same entry point.  Otherwise (gloo in the CPU tests) it falls back to
     torch.distributed point-to-point operations with the same index math.  A rank's range of one column travels
-    as messages of at most `max_message_bytes`.
+    as messages of at most `max_message_bytes`; sender and receiver must cut a range into the same pieces, so the
+    RCCL path uses the group-wide MINIMUM of the ranks' values (one all-reduce per distinct request, cached).
+    `force_torch=True` (or AESW_GATHER_PATH=torch in the environment) keeps the torch point-to-point path even with
+    the nccl backend: the RCCL leg of the C ABI has not yet run with more than one real rank.
     """
+    import os
     import torch
     import torch.distributed as dist
 
@@ -76,10 +81,16 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
     if max_message_bytes <= 0:
         raise ValueError("max_message_bytes must be positive")
     global last_gather_path
-    if ctx is not None and dist.get_backend(group) == "nccl" and all(c.is_cuda for c in columns):
+    force_torch = force_torch or os.environ.get("AESW_GATHER_PATH", "") == "torch"
+    if ctx is not None and not force_torch and dist.get_backend(group) == "nccl" and all(c.is_cuda for c in columns):
         last_gather_path = "aesw_gather_columns_device (RCCL send/recv over xGMI, C ABI)"
         comm = _aesw_comm(ctx, group)
-        comm.set_max_message(max_message_bytes)
+        akey = (id(ctx), id(group) if group is not None else None, int(max_message_bytes))
+        if akey not in _agreed_max:
+            t = torch.tensor([int(max_message_bytes)], dtype=torch.int64, device="cuda:%d" % ctx.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            _agreed_max[akey] = int(t.item())
+        comm.set_max_message(_agreed_max[akey])
         return comm.gather_columns([c[:counts[rank] * s] for c, s in zip(columns, strides)], counts, strides, root=dst)
     last_gather_path = "torch.distributed point-to-point (%s)" % dist.get_backend(group)
     total = sum(counts)

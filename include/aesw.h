@@ -166,7 +166,8 @@ int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]);
  * an encrypt call on another stream is ordered behind them with an event (no host wait).  The
  * context holds ONE scheduled key: scheduling another key while launches that use the previous one
  * are still running on a different stream races; synchronise first.  Inside a hipGraph capture the
- * scheduled-key encrypt must be captured on the stream the key was scheduled on.
+ * scheduled-key encrypt must be captured on the stream the key was scheduled on: on any other stream the
+ * call returns AESW_ERR_INVALID_ARG (the dependency on the round keys could not be captured).
  * All launch attributes (dynamic LDS sizes) are set by aesw_create(): launches never change function
  * attributes, so every *_device entry point may be captured into a hipGraph
  * (hipStreamBeginCapture on `stream`) and replayed. */
@@ -206,6 +207,28 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
                                 int layout, const uint8_t *d_x, const uint8_t *d_y,
                                 const uint8_t *d_z, const aesw_key_slab *d_key_slab, int as_fr,
                                 uint8_t *d_out, void *stream);
+
+/* One device allocation that holds every output column of a batch of n blocks ("arena"): x, y, z, optionally
+ * the ciphertext and n key slabs (w, kx, ky, kz), each column starting on a boundary of 2^arena_align_log2 bytes
+ * (option "arena_align_log2"; default 0 = auto: 1 GiB when every encrypt column of the batch is at least 64 MiB,
+ * 2 MiB otherwise).  The reference has no counterpart (its advice cells live in halo2's WitnessCollection); this is
+ * the device-side home of what FixedAes128Config::encrypt (src/aes128.rs:154-265) and schedule_keys
+ * (src/key_schedule.rs:80-96) assign.  Why one allocation: where the seven columns land decides up to 10 % of the
+ * witness kernel's launch time (profiles/r02_study/README.md 6, profiles/r03_study/): one arena was measured against
+ * seven separate allocations there.  Unused members are NULL.  aesw_columns_free releases the allocation and clears
+ * the struct; cols->base must come from aesw_columns_alloc on the same context. */
+typedef struct aesw_columns {
+    uint8_t *base;  /* the allocation */
+    uint64_t bytes; /* its size */
+    uint8_t *x;     /* n * aesw_column_stride(layout, 0); NULL for AESW_LAYOUT_VALUES */
+    uint8_t *y;
+    uint8_t *z;
+    uint8_t *ct;    /* n * 16, or NULL */
+    aesw_key_slab key; /* n key slabs, or NULLs */
+} aesw_columns;
+int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab, int with_ct,
+                       aesw_columns *out);
+int aesw_columns_free(aesw_ctx *ctx, aesw_columns *cols);
 
 /* ---- host-pointer entry points (synchronous) ----------------------------- */
 /* Same contracts with host buffers.  Blocks are cut into chunks ("chunk_blocks"
@@ -313,7 +336,10 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * 0 = one per block group), "xcd_remap" (0/1, default 1: workgroups that share an XCD take one contiguous eighth of the block
  * groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
  * pipeline, default 2^15), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
- * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1).
+ * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB
+ * workgroups: the default, 2 one-shot 16 KiB), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto).
+ * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
+ * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied).
  * Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);
