@@ -184,6 +184,30 @@ class Runner:
         return wall, ms, self.graph is not None
 
 
+def usable_cpus():
+    """CPUs this process can really run on: the affinity mask, cut down by a cgroup CPU quota if there is one
+    (a GPU box hands a 1-GPU job a share of its cores; os.cpu_count() still reports all of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(per_block_keys, n_target_seconds=12.0):
     """The CPU oracle on this host's cores: 1 thread (the reference synthesizes
     single-threaded) on a bounded sample of the headline workload's shape.  Output arrays are
@@ -229,7 +253,8 @@ def cpu_baseline(per_block_keys, n_target_seconds=12.0):
     bufs = buffers(n)
     dt1 = once(pt, keys, 1, bufs)
     cores = os.cpu_count() or 1
-    threads = min(cores, 256)  # the oracle's thread pool is capped at 256 (oracle/aesw_oracle.c)
+    usable = usable_cpus()
+    threads = max(1, min(usable, 256))  # the oracle caps its threads at 256 (oracle/aesw_oracle.c run_jobs)
     # a larger sample for the all-core leg, or thread start-up dominates it
     n_all = int(min(1 << 20, max(n, n * threads // 8)))
     pt_a, keys_a = inputs(n_all)
@@ -240,8 +265,9 @@ def cpu_baseline(per_block_keys, n_target_seconds=12.0):
         "value": n / dt1, "unit": "blocks/s", "cores": 1, "kind": "port",
         "sample": "%d blocks, %s, packed layout, oracle/aesw_oracle.c single thread (%.1f s), outputs pre-allocated and touched" % (
             n, "per-block keys + key-schedule witness" if per_block_keys else "shared key", dt1),
-        "all_cores": {"value": n_all / dtn, "cores": cores, "threads": threads,
-                      "sample": "%d blocks in %.2f s" % (n_all, dtn)},
+        "all_cores": {"value": n_all / dtn, "cores": threads, "threads": threads, "logical_cpus_of_the_host": cores,
+                      "usable_cpus": usable, "sample": "%d blocks in %.2f s" % (n_all, dtn),
+                      "note": "threads = the CPUs this job may use (affinity mask and cgroup quota), not the host's logical CPU count"},
     }
 
 

@@ -1,0 +1,114 @@
+"""Round-3 GPU tests: the arena allocator of the C ABI (aesw_columns_alloc), options read back, the refusal to
+capture a scheduled-key launch without its dependency, and the division-free one-shot assemble kernel against the
+restated synthesize()."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("layout_name", ["packed", "dense", "values"])
+def test_arena_columns_hold_a_byte_exact_witness(ctx, pkg, oracle, layout_name):
+    """aesw_columns_alloc: one allocation, aligned column bases, and a launch into it equals the oracle
+    (per-block keys + key witness + ciphertext, ragged batch)."""
+    import torch
+    lay = {"packed": pkg.LAYOUT_PACKED, "dense": pkg.LAYOUT_DENSE, "values": pkg.LAYOUT_VALUES}[layout_name]
+    olay = {"packed": ol.PACKED, "dense": ol.DENSE, "values": ol.VALUES}[layout_name]
+    rng = np.random.default_rng(31)
+    n = 3000 + 17
+    pt, keys = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    for align_log2, expect in ((0, 2 << 20), (12, 1 << 12), (21, 2 << 20)):  # auto = 2 MiB for a small batch
+        ctx.set_option("arena_align_log2", align_log2)
+        assert ctx.get_option("arena_align_log2") == align_log2
+        w = ctx.alloc_columns(n, lay, want_ct=True, key_slab=True)
+        ptrs = [t.data_ptr() for t in (w.x, w.y, w.z, w.ct, w.key.w, w.key.kx, w.key.ky, w.key.kz) if t.numel()]
+        assert all(p % expect == 0 for p in ptrs), (align_log2, [hex(p) for p in ptrs])
+        assert len(set(ptrs)) == len(ptrs)
+        sizes = [t.numel() for t in (w.x, w.y, w.z)]
+        assert sizes == [n * pkg.column_stride(lay, c) for c in range(3)]
+        for t in (w.x, w.y, w.z, w.ct, w.key.w, w.key.kx, w.key.ky, w.key.kz):
+            if t.numel():
+                t.fill_(0xA5)
+        got = ctx.encrypt_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda(), layout=lay, out=w, want_ct=True, key_slab=True)
+        torch.cuda.synchronize()
+        e = oracle.encrypt_witness(pt, keys, layout=olay)
+        k = oracle.key_schedule_witness(keys, layout=olay)
+        for c in "xyz":
+            if getattr(e, c).size:
+                assert np.array_equal(getattr(got, c).cpu().numpy(), getattr(e, c)), (layout_name, c)
+        assert np.array_equal(got.ct.cpu().numpy(), e.ct)
+        for c in ("w", "kx", "ky", "kz"):
+            assert np.array_equal(getattr(got.key, c).cpu().numpy(), getattr(k, c)), (layout_name, c)
+        ctx.free_columns(w)
+        with pytest.raises(ValueError):
+            ctx.free_columns(w)
+    ctx.set_option("arena_align_log2", 0)
+
+
+def test_arena_auto_alignment_is_1gib_for_large_batches(ctx, pkg):
+    n = 1 << 17  # z column = 76 MiB >= 64 MiB: every column base on a 1 GiB boundary
+    w = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, key_slab=True)
+    for t in (w.x, w.y, w.z, w.key.w, w.key.kx, w.key.ky, w.key.kz):
+        assert t.data_ptr() % (1 << 30) == 0
+    ctx.free_columns(w)
+
+
+def test_every_settable_option_reads_back(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    c = pkg.Context(0)
+    for name, value in (("waves_shared", 2), ("waves_pbk", 3), ("store_mode", 1), ("key_store_mode", 2), ("fr_store_mode", 0),
+                        ("fr_geometry", 2), ("grid_cap", 512), ("xcd_remap", 0), ("lds_pad", 4096), ("arena_align_log2", 16),
+                        ("chunk_blocks", 4096)):
+        c.set_option(name, value)
+        assert c.get_option(name) == value, name
+    c.set_option("force_table_path", 1)
+    assert c.get_option("force_table_path") == 1 and not c.uses_xtime_path
+    # the group size a launch really uses: requests above the packed layout's maximum of 3 are limited, 0 = auto resolved
+    c.set_option("waves_shared", 4)
+    c.set_option("waves_pbk", 0)
+    assert c.get_option("waves_shared") == 4 and c.get_option("effective_waves_shared") == 3
+    assert c.get_option("effective_waves_pbk") == 1 and c.get_option("effective_waves_key") == 4
+    with pytest.raises(pkg.AeswError):
+        c.get_option("no_such_option")
+    c.close()
+
+
+def test_scheduled_key_capture_on_a_foreign_stream_is_refused(pkg, oracle):
+    """A scheduled-key launch captured on a stream other than the key's would replay without a dependency on the round
+    keys: the C ABI returns AESW_ERR_INVALID_ARG instead of dropping the wait silently; captured on the
+    key's own stream it works and replays byte-exact."""
+    import torch
+    c = pkg.Context(0)
+    rng = np.random.default_rng(77)
+    n = 500
+    pt, key = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)
+    dpt, dkey = torch.from_numpy(pt).cuda(), torch.from_numpy(key).cuda()
+    c.schedule_key(dkey, key_slab=False)  # on torch's current (default) stream
+    torch.cuda.synchronize()
+    out = c.alloc_witness(n, pkg.LAYOUT_PACKED)
+    other = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(pkg.AeswError) as ei:
+        with torch.cuda.graph(graph, stream=other):
+            c.encrypt_witness(dpt, None, out=out)
+    assert ei.value.status == pkg.api.ERR_INVALID_ARG and "captured" in str(ei.value)
+    # the documented way: schedule on the capture stream, then capture there
+    cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        c.schedule_key(dkey, key_slab=False)
+    cap.synchronize()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2, stream=cap):
+        c.encrypt_witness(dpt, None, out=out)
+    for t in (out.x, out.y, out.z):
+        t.fill_(0)
+    graph2.replay()
+    torch.cuda.synchronize()
+    e = oracle.encrypt_witness(pt, key, layout=ol.PACKED)
+    for col in "xyz":
+        assert np.array_equal(getattr(out, col).cpu().numpy(), getattr(e, col)), col
+    c.close()
