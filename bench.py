@@ -95,8 +95,13 @@ class Runner:
         self.out_bytes_per_step = per_set
         self.nsets = max(2, min(8, -(-(640 << 20) // per_set)))
         # arena: one device allocation per set with aligned column bases (aesw_columns_alloc); else one tensor per column
-        self.sets = [(ctx.alloc_columns(n, layout, key_slab=key_slab) if arena else
-                      ctx.alloc_witness(n, layout, want_ct=False, key_slab=key_slab, n_keys=n)) for _ in range(self.nsets)]
+        self.sets, self.arena_info = [], []
+        for _ in range(self.nsets):
+            if arena:
+                self.sets.append(ctx.alloc_columns(n, layout, key_slab=key_slab))
+                self.arena_info.append(dict(ctx.last_arena))
+            else:
+                self.sets.append(ctx.alloc_witness(n, layout, want_ct=False, key_slab=key_slab, n_keys=n))
         self.lib = pkg.load_library()
         self.h = ctx._h
         self._ks = [pkg.api.KeySlab(*[t.data_ptr() for t in s.key[:4]]) if key_slab else None for s in self.sets]
@@ -393,7 +398,8 @@ def main():
     lg = a.log2_blocks or (20 if pbk else 16)
     n = 1 << lg
     # the per-rank workload at N>1 IS the N=1 headline workload, so the driver's 1/2/4/8 curve compares like with like
-    use_arena = a.arena == "on"  # "auto": separate tensors until the A/B of profiles/r03_study/arena_ab.md says otherwise
+    # "auto" = on: the probed arena beat one tensor per column on every lease of profiles/r03_study/arena_ab.md (0.80-0.86 against 0.68-0.76)
+    use_arena = a.arena != "off"
     runner = Runner(pkg, ctx, torch, n, pbk, layout, pbk, SEED + (2 if pbk else 1) + rank, arena=use_arena)
     wl = ("2^%d blocks, per-block keys (+ key-schedule witness), %s advice columns (BASELINE configs[2])" if pbk else
           "2^%d blocks, one shared key, %s advice columns (BASELINE configs[1])") % (lg, a.layout)
@@ -429,7 +435,9 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl, "blocks_per_gpu": n, "layout": a.layout, "sharding": "blocks by rank, no collective",
                    "launch": "hipGraph of %d launches" % a.steps if graphed else "host launches",
-                   "output_ring_sets": runner.nsets, "columns": "one arena per set (aesw_columns_alloc)" if use_arena else "one tensor per column"},
+                   "output_ring_sets": runner.nsets,
+                   "columns": "one probed arena per set (aesw_columns_alloc)" if use_arena else "one tensor per column",
+                   "arena_probe": runner.arena_info if use_arena else None},
         "timing": {"replays": len(replays), "reported": "median replay (exactly %d steps)" % a.steps,
                    "ms_per_step_wall": [w * 1e3 / a.steps for w, _ in replays],
                    "ms_per_step_events": [m for _, m in replays],

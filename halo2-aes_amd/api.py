@@ -50,7 +50,8 @@ class KeySlab(C.Structure):
 class Columns(C.Structure):
     """aesw_columns: one device allocation holding every output column of a batch (aesw_columns_alloc)."""
     _fields_ = [("base", C.c_void_p), ("bytes", C.c_uint64), ("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p),
-                ("ct", C.c_void_p), ("key", KeySlab)]
+                ("ct", C.c_void_p), ("key", KeySlab), ("candidates", C.c_uint32), ("chosen", C.c_uint32),
+                ("probe_us", C.c_float), ("fill_us", C.c_float)]
 
 
 class _DevView:
@@ -444,6 +445,8 @@ class Context:
                                                                    for i, c in enumerate(("kx", "ky", "kz"))], None)
         wit = Witness(x, y, z, ct, key)
         self._arenas[y.data_ptr()] = cols  # every layout has a y column
+        self.last_arena = {"candidates": int(cols.candidates), "chosen": int(cols.chosen), "probe_us": float(cols.probe_us),
+                           "fill_us": float(cols.fill_us), "bytes": int(cols.bytes)}
         return wit
 
     def free_columns(self, wit) -> None:

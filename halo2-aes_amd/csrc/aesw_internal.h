@@ -21,7 +21,7 @@ struct EncParams {
     KeyOut key;             // per-block-key mode only
     uint64_t n;
     uint32_t ngroups;       // block groups (16*waves blocks each); a workgroup strides over them
-    uint32_t xcd_remap;     // 1: workgroups that share an XCD (id % 8) take one contiguous eighth of the groups
+    uint32_t xcd_remap;     // xcd_group() mode: 0 dispatch order, 1 one contiguous eighth per XCD, C >= 2 turns of C groups
 #ifdef AESW_TRACE
     uint64_t *trace;        // tools/trace.py only: 8 x u64 per wave
 #endif
@@ -34,18 +34,18 @@ struct KeyParams {
     uint8_t *rk;  // n*176 or null
     uint64_t n;
     uint32_t ngroups;    // filled by the launcher
-    uint32_t xcd_remap;  // 1: workgroups that share an XCD (id % 8) take one contiguous eighth of the groups
+    uint32_t xcd_remap;  // xcd_group() mode, as in EncParams
 };
 
 // key mode: 0 = per-block keys, 1 = shared key expanded in the kernel, 2 = shared key scheduled earlier (p.rk)
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, int store_mode,
-                          uint32_t max_groups_in_flight, bool xcd_remap, uint32_t lds_pad, hipStream_t s);
+                          uint32_t max_groups_in_flight, uint32_t xcd_remap, uint32_t lds_pad, hipStream_t s);
 // flush-descriptor table of a layout (aesw_layout.h "scheduled flush"): size in 32-bit words, and the host-side builder
 int flush_table_words(int layout);
 void build_flush_tables(int layout, uint32_t *out);
 // hipFuncSetAttribute(max dynamic LDS) for every instantiation, once per device: called by aesw_create()
 hipError_t warm_launch_attributes();
-hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, bool xcd_remap, hipStream_t s);
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int store_mode, uint32_t xcd_remap, hipStream_t s);
 hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3, hipStream_t s);
 struct AssembleParams {
     const uint8_t *x, *y, *z;        // n_blocks slabs
@@ -60,6 +60,15 @@ struct AssembleParams {
     int packed;
 };
 hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int store_mode, hipStream_t s);
+// placement probe of aesw_columns_alloc: columns x, y, z, w, kx, ky, kz (null = absent) of n blocks
+struct ProbeParams {
+    uint8_t *col[7];
+    uint32_t stride[7];
+    uint32_t chunks[7];  // 4 KiB chunks per column (filled by the launcher for the linear fill)
+    uint64_t n;
+    uint32_t xcd_mode;  // xcd_group() mode of the context
+};
+hipError_t launch_probe(const ProbeParams &p, bool fill, hipStream_t s);
 hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int store_mode, int geometry, hipStream_t s);
 
 }  // namespace aesw

@@ -60,6 +60,23 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup id -> block group.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 names the XCD class), and each
+// XCD has its own L2: mode 0 keeps the dispatch order (all XCDs write inside one moving window), mode 1 gives every XCD one
+// contiguous eighth of the groups (eight far-apart write fronts per column), mode C >= 2 lets the XCDs take turns in
+// chunks of C groups (each XCD writes C * 16 * waves consecutive blocks, the eight fronts stay C groups apart).
+// Bijective on [0, ngroups) for every mode (speed only, never correctness).
+__device__ __forceinline__ uint32_t xcd_group(uint32_t id, uint32_t ngroups, uint32_t mode) {
+    if (mode == 0) return id;
+    const uint32_t xcd = id % 8, seq = id / 8;
+    if (mode == 1) {
+        const uint32_t q = ngroups / 8, r = ngroups % 8;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+    }
+    const uint32_t per = 8 * mode, full = ngroups / per * per;
+    if (id >= full) return id;  // the tail that does not fill a whole turn keeps the dispatch order
+    return (seq / mode * 8 + xcd) * mode + seq % mode;
+}
+
 // ---------------------------------------------------------------------------
 // sinks (see aesw_lane.h)
 // ---------------------------------------------------------------------------
@@ -112,11 +129,6 @@ template <> struct PieceT<4> { using type = uint32_t; };
 // Modes 3..5 (tools/ only) exist in -DAESW_DIAGNOSTIC builds alone: 3 = leave the flush out (compute + staging only),
 // 4 = flush only (no AES work, no staging writes: the store schedule fed from whatever LDS holds), 5 = as 4 without the
 // LDS reads.  Their output is garbage; they price the parts of a launch.
-#ifdef AESW_DIAGNOSTIC
-constexpr int NT_MODES = 6;
-#else
-constexpr int NT_MODES = 3;
-#endif
 template <int MODE>
 __device__ __forceinline__ void gstore(u32x4 *p, const u32x4 &v) {
     if (MODE == 3) return;
@@ -134,12 +146,15 @@ __device__ __forceinline__ void gstore(u32x2 *p, const u32x2 &v) {
     else *p = v;
 }
 // wave-uniform base (SGPR pair) + 32-bit byte offset per lane: no 64-bit address arithmetic per piece
+// All three flavours go through the same asm form (SGPR base + VGPR offset), so that they differ in the cache-policy
+// bits and in nothing else: written as C++ stores the plain and nontemporal variants needed 60 more VGPRs for 64-bit
+// per-piece addresses (258-346 registers: one wave per SIMD), which made every flavour A/B a residency A/B too.
 template <int MODE>
 __device__ __forceinline__ void gstore_at(uint8_t *base, uint32_t off, const u32x4 &v) {
     if (MODE == 3) return;
     if (MODE == 2 || MODE >= 4) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base) : "memory");
-    else if (MODE == 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(base + off));
-    else *reinterpret_cast<u32x4 *>(base + off) = v;
+    else if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(off), "v"(v), "s"(base) : "memory");
 }
 __device__ __forceinline__ uint8_t *uniform_ptr(uint8_t *p) {
     const uint64_t v = reinterpret_cast<uint64_t>(p);
@@ -366,7 +381,7 @@ enum : int { KM_PBK = 0, KM_SHARED = 1, KM_PRE = 2 };
 #endif
 
 template <int L, bool XT, int KM, bool KEMIT, int NT>
-__global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
+__global__ void __launch_bounds__(256, (L == DENSE ? 1 : 2)) encrypt_kernel(const EncParams a) {
     constexpr bool PBK = KM == KM_PBK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using G = Geo<L>;
@@ -393,11 +408,7 @@ __global__ void __launch_bounds__(256) encrypt_kernel(const EncParams a) {
     // the first group's inputs first, so their latency hides behind the table load
     // Optional XCD-aware order (workgroups are dealt round-robin over the 8 XCDs): ids that share an
     // XCD walk one contiguous eighth of the block groups.  Bijective for any ngroups (speed only).
-    auto remap = [&](uint32_t id) -> uint32_t {
-        if (!a.xcd_remap) return id;
-        const uint32_t q = a.ngroups / 8, r = a.ngroups % 8, xcd = id % 8;
-        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + id / 8;
-    };
+    auto remap = [&](uint32_t id) -> uint32_t { return xcd_group(id, a.ngroups, a.xcd_remap); };
     auto group_blk0 = [&](uint32_t grp) { return ((uint64_t)remap(grp) * waves + wave) * BPW; };
     auto group_nvalid = [&](uint64_t b0) {
         const int64_t left = (int64_t)a.n - (int64_t)b0;
@@ -556,11 +567,7 @@ __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     const Tables<XT> tab{lds};
     const uint32_t stage = TAB_BYTES + wave * WAVE_LDS;
     const uint32_t rk_w = stage + St::KEY_BYTES;
-    uint32_t grp = blockIdx.x;
-    if (a.xcd_remap) {  // as in encrypt_kernel: an XCD's workgroups write one contiguous eighth of every column
-        const uint32_t q = a.ngroups / 8, r = a.ngroups % 8, xcd = grp % 8;
-        grp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + grp / 8;
-    }
+    const uint32_t grp = xcd_group(blockIdx.x, a.ngroups, a.xcd_remap);  // as in encrypt_kernel
     const uint64_t blk0 = ((uint64_t)grp * waves + wave) * BPW;
     const int64_t left = (int64_t)a.n - (int64_t)blk0;
     const int nvalid = left >= BPW ? BPW : (left > 0 ? (int)left : 0);
@@ -723,6 +730,69 @@ __global__ void __launch_bounds__(256) assemble_kernel(const AssembleParams a) {
 }
 
 // ---------------------------------------------------------------------------
+// placement probe (aesw_columns_alloc): a store-only emulation of encrypt_kernel's pattern and a linear fill
+// ---------------------------------------------------------------------------
+// probe_fronts: one wave per 16 blocks, in xcd_group() order; the key columns leave as one contiguous range per
+// column, the encrypt columns in ten slices cut on whole KiB, exactly the traffic shape of a launch (tools/allocbench.hip
+// shows the product's time follows this emulation's within a few per cent on every backing).  The values are garbage:
+// the arena is uninitialised memory when it is probed.
+__global__ void __launch_bounds__(64) probe_fronts_kernel(const ProbeParams a) {
+    const int lane = threadIdx.x;
+    const uint32_t grp = xcd_group(blockIdx.x, gridDim.x, a.xcd_mode);
+    const uint64_t blk0 = (uint64_t)grp * BPW;
+    if (blk0 >= a.n) return;
+    const int nb = a.n - blk0 < (uint64_t)BPW ? (int)(a.n - blk0) : BPW;
+    const u32x4 v = {0x5a5a5a5au, (uint32_t)grp, (uint32_t)lane, 0xa5a5a5a5u};
+    for (int c = 3; c < 7; ++c) {
+        if (!a.col[c]) continue;
+        uint8_t *g = a.col[c] + blk0 * a.stride[c];
+        const int len = nb * (int)a.stride[c] / 16 * 16;
+        for (int p = lane * 16; p < len; p += LANES * 16) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(g + p));
+    }
+    for (int r = 0; r < 10; ++r)
+        for (int c = 0; c < 3; ++c) {
+            if (!a.col[c]) continue;
+            uint8_t *g = a.col[c] + blk0 * a.stride[c];
+            const int len = nb * (int)a.stride[c] / 16 * 16;
+            const int lo = len / 10 * r / 1024 * 1024, hi = r == 9 ? len : len / 10 * (r + 1) / 1024 * 1024;
+            for (int p = lo + lane * 16; p < hi; p += LANES * 16) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(g + p));
+        }
+}
+// probe_fill: workgroup i writes the 4 KiB chunk i of the same columns, one after the other (the fastest writer the part has)
+__global__ void __launch_bounds__(256) probe_fill_kernel(const ProbeParams a) {
+    uint32_t chunk = blockIdx.x;
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)  // chunks[] is 0 for an absent column
+        if (c == i && chunk >= a.chunks[i]) { chunk -= a.chunks[i]; c = i + 1; }
+    const uint64_t p = (uint64_t)chunk * 4096 + threadIdx.x * 16;
+    const u32x4 v = {1u, 2u, 3u, threadIdx.x};
+    if (p + 16 <= a.n * a.stride[c]) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(a.col[c] + p));
+}
+
+hipError_t launch_probe(const ProbeParams &p0, bool fill, hipStream_t s) {
+    if (p0.n == 0) return hipSuccess;
+    ProbeParams p = p0;
+    if (fill) {
+        uint64_t chunks = 0;
+        for (int c = 0; c < 7; ++c) {
+            const uint64_t k = p.col[c] ? (p.n * p.stride[c] + 4095) / 4096 : 0;
+            if (k > 0x7fffffffull) return hipErrorInvalidValue;
+            p.chunks[c] = (uint32_t)k;
+            chunks += k;
+        }
+        if (chunks == 0) return hipSuccess;
+        if (chunks > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(probe_fill_kernel, dim3((unsigned)chunks), dim3(256), 0, s, p);
+    } else {
+        const uint64_t groups = (p.n + BPW - 1) / BPW;
+        if (groups > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(probe_fronts_kernel, dim3((unsigned)groups), dim3(LANES), 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 // Dynamic LDS above 48 KiB needs the attribute once per (kernel, device); remember
@@ -744,14 +814,14 @@ static hipError_t allow_large_lds(const void *fn, size_t lds) {
 }
 
 template <int L, bool XT, int KM, bool KEMIT, int NT>
-static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool xr, uint32_t lds_pad, hipStream_t stream) {
+static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, uint32_t xr, uint32_t lds_pad, hipStream_t stream) {
     const int bpg = waves * BPW;
     const uint64_t groups = (p0.n + bpg - 1) / bpg;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
     EncParams p = p0;
     p.ngroups = (uint32_t)groups;
-    p.xcd_remap = xr ? 1u : 0u;
+    p.xcd_remap = xr;
     const unsigned grid = cap && cap < groups ? cap : (unsigned)groups;
     const size_t lds = TAB_BYTES + RKS_BYTES + (size_t)waves * enc_wave_lds<L>(KEMIT) + lds_pad;
     // flush descriptors carry 16-bit LDS addresses: a group's staging must end below 64 KiB
@@ -766,7 +836,7 @@ static hipError_t launch_enc(const EncParams &p0, int waves, uint32_t cap, bool 
 }
 
 template <int L, bool XT, int KM, bool KEMIT>
-static hipError_t launch_enc_nt(const EncParams &p, int waves, int nt, uint32_t cap, bool xr, uint32_t pad, hipStream_t s) {
+static hipError_t launch_enc_nt(const EncParams &p, int waves, int nt, uint32_t cap, uint32_t xr, uint32_t pad, hipStream_t s) {
 #ifdef AESW_DIAGNOSTIC
     if (nt == 3) return launch_enc<L, XT, KM, KEMIT, 3>(p, waves, cap, xr, pad, s);
     if (nt == 4) return launch_enc<L, XT, KM, KEMIT, 4>(p, waves, cap, xr, pad, s);
@@ -778,18 +848,18 @@ static hipError_t launch_enc_nt(const EncParams &p, int waves, int nt, uint32_t 
 }
 
 template <int L, bool XT>
-static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, int nt, uint32_t cap, bool xr, uint32_t pad, hipStream_t s) {
+static hipError_t launch_enc_mode(const EncParams &p, int km, bool kemit, int waves, int nt, uint32_t cap, uint32_t xr, uint32_t pad, hipStream_t s) {
     if (km == KM_PRE) return launch_enc_nt<L, XT, KM_PRE, false>(p, waves, nt, cap, xr, pad, s);
     if (km == KM_SHARED) return launch_enc_nt<L, XT, KM_SHARED, false>(p, waves, nt, cap, xr, pad, s);
     return kemit ? launch_enc_nt<L, XT, KM_PBK, true>(p, waves, nt, cap, xr, pad, s) : launch_enc_nt<L, XT, KM_PBK, false>(p, waves, nt, cap, xr, pad, s);
 }
 
 hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, bool kemit, int waves, int nt,
-                          uint32_t max_groups_in_flight, bool xcd_remap, uint32_t pad, hipStream_t s) {
+                          uint32_t max_groups_in_flight, uint32_t xcd_remap, uint32_t pad, hipStream_t s) {
     if (waves < 1 || waves > 4 || keymode < 0 || keymode > 2) return hipErrorInvalidValue;
     const uint32_t cap = max_groups_in_flight;
     // a striding workgroup keeps its XCD class (id % 8) only when the stride is a multiple of 8
-    const bool xr = xcd_remap && (cap == 0 || cap % 8 == 0);
+    const uint32_t xr = (cap == 0 || cap % 8 == 0) ? xcd_remap : 0u;
     if (layout == DENSE)
         return xt ? launch_enc_mode<DENSE, true>(p, keymode, kemit, waves, nt, cap, xr, pad, s)
                   : launch_enc_mode<DENSE, false>(p, keymode, kemit, waves, nt, cap, xr, pad, s);
@@ -801,14 +871,14 @@ hipError_t launch_encrypt(const EncParams &p, int layout, bool xt, int keymode, 
 }
 
 template <int L, bool XT, int NT>
-static hipError_t launch_key_t(const KeyParams &p0, int waves, bool xr, hipStream_t stream) {
+static hipError_t launch_key_t(const KeyParams &p0, int waves, uint32_t xr, hipStream_t stream) {
     const int bpg = waves * BPW;
     const uint64_t groups = (p0.n + bpg - 1) / bpg;
     if (groups == 0) return hipSuccess;
     if (groups > 0x7fffffffull) return hipErrorInvalidValue;
     KeyParams p = p0;
     p.ngroups = (uint32_t)groups;
-    p.xcd_remap = xr ? 1u : 0u;
+    p.xcd_remap = xr;
     const size_t lds = TAB_BYTES + (size_t)waves * (Stage<L>::KEY_BYTES + Stage<L>::RK_BYTES_W);
     {
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&key_kernel<L, XT, NT>), lds);
@@ -819,11 +889,11 @@ static hipError_t launch_key_t(const KeyParams &p0, int waves, bool xr, hipStrea
 }
 
 template <int L, bool XT>
-static hipError_t launch_key_nt(const KeyParams &p, int waves, int nt, bool xr, hipStream_t s) {
+static hipError_t launch_key_nt(const KeyParams &p, int waves, int nt, uint32_t xr, hipStream_t s) {
     return nt == 2 ? launch_key_t<L, XT, 2>(p, waves, xr, s) : nt == 1 ? launch_key_t<L, XT, 1>(p, waves, xr, s) : launch_key_t<L, XT, 0>(p, waves, xr, s);
 }
 
-hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int nt, bool xcd_remap, hipStream_t s) {
+hipError_t launch_key(const KeyParams &p, int layout, bool xt, int waves, int nt, uint32_t xcd_remap, hipStream_t s) {
     if (waves < 1 || waves > 4) return hipErrorInvalidValue;
     if (layout == DENSE) return xt ? launch_key_nt<DENSE, true>(p, waves, nt, xcd_remap, s) : launch_key_nt<DENSE, false>(p, waves, nt, xcd_remap, s);
     return xt ? launch_key_nt<PACKED, true>(p, waves, nt, xcd_remap, s) : launch_key_nt<PACKED, false>(p, waves, nt, xcd_remap, s);

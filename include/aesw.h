@@ -208,23 +208,39 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
                                 const uint8_t *d_z, const aesw_key_slab *d_key_slab, int as_fr,
                                 uint8_t *d_out, void *stream);
 
-/* One device allocation that holds every output column of a batch of n blocks ("arena"): x, y, z, optionally
- * the ciphertext and n key slabs (w, kx, ky, kz), each column starting on a boundary of 2^arena_align_log2 bytes
- * (option "arena_align_log2"; default 0 = auto: 1 GiB when every encrypt column of the batch is at least 64 MiB,
- * 2 MiB otherwise).  The reference has no counterpart (its advice cells live in halo2's WitnessCollection); this is
- * the device-side home of what FixedAes128Config::encrypt (src/aes128.rs:154-265) and schedule_keys
- * (src/key_schedule.rs:80-96) assign.  Why one allocation: where the seven columns land decides up to 10 % of the
- * witness kernel's launch time (profiles/r02_study/README.md 6, profiles/r03_study/): one arena was measured against
- * seven separate allocations there.  Unused members are NULL.  aesw_columns_free releases the allocation and clears
- * the struct; cols->base must come from aesw_columns_alloc on the same context. */
+/* The device-side home of what FixedAes128Config::encrypt (src/aes128.rs:154-265) and schedule_keys
+ * (src/key_schedule.rs:80-96) assign: every output column of a batch of n blocks -- x, y, z, optionally the
+ * ciphertext and n key slabs (w, kx, ky, kz) -- allocated together ("arena").  The reference has no counterpart (its
+ * advice cells live in halo2's WitnessCollection).
+ *
+ * Placement probing.  Measured on MI355X (profiles/r03_study/README.md): how fast the witness kernel's store pattern --
+ * thousands of waves, each filling its own 16-block range of seven columns -- runs depends on WHICH physical memory
+ * backs the columns: the same kernel, inputs and virtual layout took 600 us on one allocation and 770 us on the next,
+ * stable for the life of an allocation, while a linear fill of the same buffers took 587 us on both.  The property
+ * belongs to the combination of columns (256 MiB tiles that all look fast in isolation combine into slow sets) and no
+ * virtual-address rule predicts it, so the arena is chosen by measurement, one column at a time, largest first: up to
+ * "arena_probe" candidate backings per column (default 8 for batches of at least 2^18 blocks; 0 = off: one hipMalloc,
+ * columns on 2^arena_align_log2-byte boundaries, default 2 MiB) are built with the virtual-memory API from physical
+ * chunks of 2 ... 32 MiB; a store-only emulation of the kernel's pattern over the columns placed so far plus the
+ * candidate is timed against a linear fill of the same bytes; the first candidate whose pattern runs as fast as its
+ * fill is kept, otherwise the one with the best ratio; the rest go back to the driver when the search is over.
+ * probe_us / fill_us report the two times for the complete set as finally placed.  Probing writes garbage into the
+ * (uninitialised) columns and takes 0.1 - 0.5 s for a 2^20-block set.  With probing every column is its own 2 MiB
+ * aligned virtual range; `base` is then only the handle the arena is freed by, `bytes` the sum of the ranges.
+ * Unused members are NULL.  aesw_columns_free releases the arena and clears the struct; cols must come from
+ * aesw_columns_alloc on the same context. */
 typedef struct aesw_columns {
-    uint8_t *base;  /* the allocation */
-    uint64_t bytes; /* its size */
+    uint8_t *base;  /* the allocation (arena_probe 0) / the handle of the arena */
+    uint64_t bytes; /* device memory held */
     uint8_t *x;     /* n * aesw_column_stride(layout, 0); NULL for AESW_LAYOUT_VALUES */
     uint8_t *y;
     uint8_t *z;
     uint8_t *ct;    /* n * 16, or NULL */
     aesw_key_slab key; /* n key slabs, or NULLs */
+    uint32_t candidates; /* column backings probed in all (0: probing off) */
+    uint32_t chosen;     /* reserved (0) */
+    float probe_us;      /* store-pattern emulation over the set as placed, microseconds per pass */
+    float fill_us;       /* a linear fill of the same bytes */
 } aesw_columns;
 int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab, int with_ct,
                        aesw_columns *out);
@@ -332,12 +348,13 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
 /* ---- tuning / introspection (bench.py, tests) ----------------------------- */
 /* name: "waves_shared" / "waves_pbk" (waves per group for launches with one key / with per-block keys; 0 = auto, 1..4,
  * silently limited to what keeps a group's LDS staging below 64 KiB: 3 for the packed layout, 2 dense, 4 values-only),
- * "store_mode" (0 plain, 1 nontemporal, 2 write-through sc1: the default), "nt_stores" (0/1), "grid_cap" (max workgroups per launch,
- * 0 = one per block group), "xcd_remap" (0/1, default 1: workgroups that share an XCD take one contiguous eighth of the block
- * groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
+ * "store_mode" (0 plain, 1 nontemporal: the default, 2 write-through sc1), "nt_stores" (0/1), "grid_cap" (max workgroups per launch,
+ * 0 = one per block group), "xcd_remap" (which block groups the workgroups of one XCD take: 0 = dispatch order, 1 = one contiguous eighth of
+ * the block groups per XCD (default), C >= 2 = the XCDs take turns in chunks of C groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
  * pipeline, default 2^15), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB
- * workgroups: the default, 2 one-shot 16 KiB), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto).
+ * workgroups: the default, 2 one-shot 16 KiB), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto), "arena_probe" (candidate backings
+ * aesw_columns_alloc measures, -1 = auto: 8 for batches of at least 2^18 blocks, 0 = none: one hipMalloc).
  * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
  * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied).
  * Unknown -> INVALID_ARG */

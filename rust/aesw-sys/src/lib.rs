@@ -99,6 +99,10 @@ pub struct aesw_columns {
     pub z: *mut u8,
     pub ct: *mut u8,
     pub key: aesw_key_slab,
+    pub candidates: u32,
+    pub chosen: u32,
+    pub probe_us: f32,
+    pub fill_us: f32,
 }
 
 pub type aesw_chunk_fn = unsafe extern "C" fn(

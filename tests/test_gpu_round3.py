@@ -19,7 +19,8 @@ def test_arena_columns_hold_a_byte_exact_witness(ctx, pkg, oracle, layout_name):
     rng = np.random.default_rng(31)
     n = 3000 + 17
     pt, keys = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, (n, 16), dtype=np.uint8)
-    for align_log2, expect in ((0, 2 << 20), (12, 1 << 12), (21, 2 << 20)):  # auto = 2 MiB for a small batch
+    assert ctx.get_option("arena_probe") == -1  # auto: no probing for a batch this small, one hipMalloc
+    for align_log2, expect in ((0, 2 << 20), (12, 1 << 12), (21, 2 << 20)):  # auto = 2 MiB
         ctx.set_option("arena_align_log2", align_log2)
         assert ctx.get_option("arena_align_log2") == align_log2
         w = ctx.alloc_columns(n, lay, want_ct=True, key_slab=True)
@@ -47,12 +48,34 @@ def test_arena_columns_hold_a_byte_exact_witness(ctx, pkg, oracle, layout_name):
     ctx.set_option("arena_align_log2", 0)
 
 
-def test_arena_auto_alignment_is_1gib_for_large_batches(ctx, pkg):
-    n = 1 << 17  # z column = 76 MiB >= 64 MiB: every column base on a 1 GiB boundary
-    w = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, key_slab=True)
-    for t in (w.x, w.y, w.z, w.key.w, w.key.kx, w.key.ky, w.key.kz):
-        assert t.data_ptr() % (1 << 30) == 0
-    ctx.free_columns(w)
+def test_probed_arena_holds_a_byte_exact_witness(ctx, pkg, oracle):
+    """aesw_columns_alloc with placement probing (virtual-memory API, candidates timed with the store-pattern emulation):
+    the chosen arena is ordinary device memory -- a launch into it equals the oracle, it can be read back, freed and
+    allocated again; the struct reports how many candidates were measured and the two times of the one kept."""
+    import torch
+    rng = np.random.default_rng(33)
+    n = (1 << 18) + 16 * 3 + 5  # auto probing starts at 2^18 blocks
+    pt, keys = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    e = oracle.encrypt_witness(pt, keys, layout=ol.PACKED)
+    k = oracle.key_schedule_witness(keys, layout=ol.PACKED)
+    dpt, dkeys = torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda()
+    for probe in (-1, 2, 1):
+        ctx.set_option("arena_probe", probe)
+        w = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
+        info = ctx.last_arena
+        assert 7 <= info["candidates"] <= 7 * (8 if probe < 0 else probe)  # seven probed columns, 1 .. arena_probe candidates each
+        assert info["probe_us"] > 0 and info["fill_us"] > 0 and info["probe_us"] < 3 * info["fill_us"]
+        for t in (w.x, w.y, w.z, w.key.w, w.key.kx, w.key.ky, w.key.kz):
+            assert t.data_ptr() % (2 << 20) == 0
+        got = ctx.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, want_ct=True, key_slab=True)
+        torch.cuda.synchronize()
+        for c in "xyz":
+            assert np.array_equal(getattr(got, c).cpu().numpy(), getattr(e, c)), c
+        assert np.array_equal(got.ct.cpu().numpy(), e.ct)
+        for c in ("w", "kx", "ky", "kz"):
+            assert np.array_equal(getattr(got.key, c).cpu().numpy(), getattr(k, c)), c
+        ctx.free_columns(w)
+    ctx.set_option("arena_probe", -1)
 
 
 def test_every_settable_option_reads_back(pkg):
@@ -61,7 +84,7 @@ def test_every_settable_option_reads_back(pkg):
         pytest.skip("no GPU")
     c = pkg.Context(0)
     for name, value in (("waves_shared", 2), ("waves_pbk", 3), ("store_mode", 1), ("key_store_mode", 2), ("fr_store_mode", 0),
-                        ("fr_geometry", 2), ("grid_cap", 512), ("xcd_remap", 0), ("lds_pad", 4096), ("arena_align_log2", 16),
+                        ("fr_geometry", 2), ("grid_cap", 512), ("xcd_remap", 0), ("xcd_remap", 64), ("lds_pad", 4096), ("arena_align_log2", 16), ("arena_probe", 3),
                         ("chunk_blocks", 4096)):
         c.set_option(name, value)
         assert c.get_option(name) == value, name

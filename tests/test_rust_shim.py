@@ -30,9 +30,9 @@ REFERENCE = Path("/root/reference")
 # ---------------------------------------------------------------------------------------------------------------------
 C_INT = {"int": ("int", "c_int"), "uint8_t": ("int", "u8"), "uint16_t": ("int", "u16"), "uint32_t": ("int", "u32"),
          "uint64_t": ("int", "u64"), "int32_t": ("int", "i32"), "int64_t": ("int", "i64"), "size_t": ("int", "usize"),
-         "char": ("int", "c_char"), "void": ("void",)}
+         "char": ("int", "c_char"), "void": ("void",), "float": ("float", "f32")}
 RUST_INT = {"c_int": ("int", "c_int"), "u8": ("int", "u8"), "u16": ("int", "u16"), "u32": ("int", "u32"), "u64": ("int", "u64"),
-            "i32": ("int", "i32"), "i64": ("int", "i64"), "usize": ("int", "usize"), "c_char": ("int", "c_char"), "c_void": ("void",)}
+            "i32": ("int", "i32"), "i64": ("int", "i64"), "usize": ("int", "usize"), "c_char": ("int", "c_char"), "c_void": ("void",), "f32": ("float", "f32")}
 NAMED = ("aesw_ctx", "aesw_comm", "aesw_key_slab", "aesw_copy_edge", "aesw_stream_stats", "aesw_columns")
 CALLBACKS = ("aesw_chunk_fn", "aesw_column_fn")
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""the headline workload (2^20 blocks, per-block keys + key witness, packed) with its output columns
+  tensors   as separate torch tensors (what bench.py did until round 3)
+  malloc    in one hipMalloc arena (aesw_columns_alloc, arena_probe 0)
+  set       in a probed arena, candidates = whole sets   (arena_unit 0)
+  column    in a probed arena, candidates = single columns, greedy (arena_unit 1)
+ONE variant per process (who allocates first gets different memory: variants in one process are not comparable); run the
+four back to back on one lease: tools/arena_ab.sh.  bench.py's own Runner (hipGraph of `steps` launches, HIP events).
+usage: arena_ab.py VARIANT [LOG2N] [store_mode]"""
+import statistics
+import sys
+import time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+ge.build()
+pkg = ge.load_package()
+import bench  # noqa: E402
+
+variant = sys.argv[1]
+lg = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+n = 1 << lg
+ctx = pkg.Context(0)
+if len(sys.argv) > 3:
+    ctx.set_option("store_mode", int(sys.argv[3]))
+L = pkg.LAYOUT_PACKED
+t0 = time.perf_counter()
+if variant == "tensors":
+    r = bench.Runner(pkg, ctx, torch, n, True, L, True, 11, arena=False)
+else:
+    ctx.set_option("arena_probe", 0 if variant == "malloc" else -1)
+    ctx.set_option("arena_unit", 1 if variant == "column" else 0)
+    r = bench.Runner(pkg, ctx, torch, n, True, L, True, 11, arena=True)
+torch.cuda.synchronize()
+setup = time.perf_counter() - t0
+v = []
+for rnd in range(5):
+    w, ms, _ = r.run(20, 3, True)
+    v.append(ms * 1e3)
+med = statistics.median(v)
+info = " ".join("[%d cand, probe %.0f / fill %.0f us]" % (a["candidates"], a["probe_us"], a["fill_us"]) for a in r.arena_info if a["candidates"])
+print("%-8s median %8.2f us  min %8.2f  max %8.2f  -> %6.0f GB/s  (%.3f of 8 TB/s)  set-up %.2f s  %s" % (
+    variant, med, min(v), max(v), 3992 * n / med / 1e3, 3992 * n / med / 8e6, setup, info))

@@ -1,0 +1,105 @@
+// probebench.hip -- round 3: is "how fast the many-front write pattern runs" a property of an ALLOCATION?
+// N separate hipMalloc buffers of the same size; on each, a one-column version of the round-sliced emulation (a wave owns
+// 16 x stride bytes and writes them in ten slices; 2^20/col_div "blocks") and a linear 4 KiB fill, several times, in an
+// interleaved order.  If the per-buffer times are stable over repeats and differ between buffers, placement is a property
+// of the allocation and can be PROBED: allocate candidates, keep the fast ones.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probebench tools/probebench.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ void st(uint8_t *p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+__global__ void __launch_bounds__(64) k_fronts(uint8_t *base, uint32_t nblk, int stride) {
+    const int lane = threadIdx.x;
+    const uint32_t ng = gridDim.x, id = blockIdx.x, q = ng / 8, rr = ng % 8, x = id % 8;
+    const uint32_t grp = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + id / 8;
+    const size_t blk0 = (size_t)grp * 16;
+    if (blk0 >= nblk) return;
+    u32x4 v = {1u, 2u, 3u, (uint32_t)lane};
+    uint8_t *g = base + blk0 * stride;
+    const int len = 16 * stride;
+    for (int r = 0; r < 10; ++r) {
+        const int lo = len / 10 * r / 1024 * 1024, hi = r == 9 ? len : len / 10 * (r + 1) / 1024 * 1024;
+        for (int p = lo + lane * 16; p < hi; p += 64 * 16) st(g + p, v);
+    }
+}
+__global__ void __launch_bounds__(256) k_fill(uint8_t *out, size_t total) {
+    const size_t p = (size_t)blockIdx.x * 4096 + (size_t)threadIdx.x * 16;
+    u32x4 v = {1u, 2u, 3u, threadIdx.x};
+    if (p < total) st(out + p, v);
+}
+
+int main(int argc, char **argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 16;
+    const int stride = argc > 2 ? atoi(argv[2]) : 1360;
+    const uint32_t nblk = 1u << 20;
+    const size_t bytes = (size_t)nblk * stride;
+    std::vector<uint8_t *> buf(N);
+    for (auto &b : buf) CK(hipMalloc(&b, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto timeit = [&](auto launch) {
+        launch();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 4; ++i) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3 / 4;
+    };
+    printf("%d buffers of %zu bytes (stride %d): many-front pattern / linear fill, us per pass, three repeats\n", N, bytes, stride);
+    std::vector<std::vector<double>> tf(N), tl(N);
+    for (int rep = 0; rep < 3; ++rep)
+        for (int i = 0; i < N; ++i) {
+            tf[i].push_back(timeit([&] { hipLaunchKernelGGL(k_fronts, dim3(nblk / 16), dim3(64), 0, 0, buf[i], nblk, stride); }));
+            tl[i].push_back(timeit([&] { hipLaunchKernelGGL(k_fill, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, 0, buf[i], bytes); }));
+        }
+    for (int i = 0; i < N; ++i)
+        printf("buffer %2d  %p   fronts %7.1f %7.1f %7.1f  (%5.0f GB/s)   fill %7.1f %7.1f %7.1f  (%5.0f GB/s)\n", i, (void *)buf[i], tf[i][0], tf[i][1], tf[i][2],
+               bytes / tf[i][1] / 1e3, tl[i][0], tl[i][1], tl[i][2], bytes / tl[i][1] / 1e3);
+    for (auto b : buf) CK(hipFree(b));
+    // ---- tiles: the same question at finer granularity, with the virtual-memory API (what a probing allocator would use)
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t tile : {(size_t)64 << 20, (size_t)256 << 20, (size_t)1024 << 20}) {
+        const int nt = (int)(((size_t)24 << 30) / tile);  // 24 GiB worth of tiles
+        void *va = nullptr;
+        CK(hipMemAddressReserve(&va, tile * nt, 0, nullptr, 0));
+        for (int i = 0; i < nt; ++i) {
+            hipMemGenericAllocationHandle_t h;
+            CK(hipMemCreate(&h, tile, &prop, 0));
+            CK(hipMemMap((uint8_t *)va + (size_t)i * tile, tile, 0, h, 0));
+            CK(hipMemRelease(h));
+        }
+        CK(hipMemSetAccess(va, tile * nt, &acc, 1));
+        const uint32_t tb = (uint32_t)(tile / stride / 16 * 16);  // blocks per tile
+        printf("tiles of %zu MiB (%d of them): fronts/fill time ratio per tile (two repeats)\n", tile >> 20, nt);
+        std::vector<double> r1(nt), r2(nt);
+        for (int rep = 0; rep < 2; ++rep)
+            for (int i = 0; i < nt; ++i) {
+                uint8_t *b = (uint8_t *)va + (size_t)i * tile;
+                const double f = timeit([&] { hipLaunchKernelGGL(k_fronts, dim3(tb / 16), dim3(64), 0, 0, b, tb, stride); });
+                const double l = timeit([&] { hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)tb * stride + 4095) / 4096)), dim3(256), 0, 0, b, (size_t)tb * stride); });
+                (rep ? r2 : r1)[i] = f / l;
+            }
+        for (int i = 0; i < nt; ++i) printf("%s%.2f/%.2f", i % 16 ? "  " : "\n  ", r1[i], r2[i]);
+        printf("\n");
+        CK(hipMemUnmap(va, tile * nt));
+        CK(hipMemAddressFree(va, tile * nt));
+    }
+    return 0;
+}

@@ -144,9 +144,19 @@ int main(int argc, char **argv) {
     CK(hipMemset(pt, 0x5a, (size_t)nmax * 16));
     CK(hipMemset(keys, 0xc3, (size_t)nmax * 16));
     size_t col_skew = 0;  // "sizes" mode: extra bytes between consecutive columns of a set
+    // "sizes" mode, second question: ONE allocation per buffer set (columns carved back to back) or one hipMalloc per column?
+    uint8_t *sep[NBUF][NS];
+    bool separate = false;
+    if (sizes_mode)
+        for (auto &set : sep)
+            for (int c = 0; c < NS; ++c) CK(hipMalloc(&set[c], (size_t)nmax * h_stride[c] + (2 << 20)));
     auto cols_of = [&](int i, uint32_t first_block) {
         Cols c;
         uint8_t *b = buf[i % NBUF];
+        if (separate) {
+            for (int s = 0; s < NS; ++s) c.base[s] = sep[i % NBUF][s] + (size_t)first_block * h_stride[s];
+            return c;
+        }
         for (int s = 0; s < NS; ++s) { c.base[s] = b + (size_t)first_block * h_stride[s]; b += (size_t)nblk * h_stride[s] + col_skew; }
         return c;
     };
@@ -180,7 +190,7 @@ int main(int argc, char **argv) {
 
     // ---- the product through the C ABI (same process) ----------------------------------------------------------
     void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
-    aesw_ctx *ctx[2] = {nullptr, nullptr};
+    aesw_ctx *ctx[3] = {nullptr, nullptr, nullptr};  // product (sc1), stores only, product with nontemporal stores
     decltype(&aesw_encrypt_witness_device) enc = nullptr;
     if (lib) {
         auto create = reinterpret_cast<decltype(&aesw_create)>(dlsym(lib, "aesw_create"));
@@ -192,9 +202,11 @@ int main(int argc, char **argv) {
             m2[i] = (uint8_t)((i << 1) ^ ((i & 0x80) ? 0x1b : 0));
             m3[i] = (uint8_t)(m2[i] ^ i);
         }
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < 3; ++k) {
             if (create(&ctx[k], 0, sbox, m2, m3) != AESW_OK) { printf("aesw_create failed\n"); return 1; }
         }
+        setopt(ctx[0], "store_mode", 2);
+        setopt(ctx[2], "store_mode", 1);
         if (setopt(ctx[1], "store_mode", 5) != AESW_OK) { printf("%s is not a -DAESW_DIAGNOSTIC build: no stores-only mode\n", libpath); ctx[1] = nullptr; }
     } else {
         printf("no %s (%s): product rows skipped\n", libpath, dlerror());
@@ -253,18 +265,21 @@ int main(int argc, char **argv) {
         // back starts on a multiple of 16 MiB: 56 fronts that advance in lockstep at a fixed power-of-two distance.
         const uint32_t sizes[] = {1u << 20, (1u << 20) - 16 * 8 * 5, (1u << 20) + 16 * 8 * 7, 1000000u - 1000000u % 16, (1u << 20) - 16 * 8 * 64, 1u << 20};
         for (int round = 0; round < 2; ++round)
-            for (size_t skew : {(size_t)0, (size_t)(3 << 20) + 45056}) {
-                col_skew = skew;
+            for (size_t skew : {(size_t)0, (size_t)(3 << 20) + 45056, (size_t)1}) {
+                separate = skew == 1;  // third variant: one hipMalloc per column
+                col_skew = separate ? 0 : skew;
                 for (uint32_t nb : sizes) {
                     nblk = nb;
                     bytes = (size_t)nblk * bpb;
                     alg = (size_t)nblk * 3992;
                     char name[200];
-                    snprintf(name, sizeof name, "n = %8u blocks (%5u groups per XCD), column skew %8zu B: PRODUCT", nblk, nblk / 16 / 8, skew);
+                    snprintf(name, sizeof name, "n = %8u blocks (%5u groups per XCD), %s%8zu B: PRODUCT", nblk, nblk / 16 / 8, separate ? "one hipMalloc per column, " : "one allocation, column skew ", skew);
                     if (ctx[0]) report(name, timeit(reps, [&](int i, hipStream_t s) { product(0, i, s); }));
-                    snprintf(name, sizeof name, "n = %8u blocks (%5u groups per XCD), column skew %8zu B: PRODUCT stores only", nblk, nblk / 16 / 8, skew);
+                    snprintf(name, sizeof name, "n = %8u blocks (%5u groups per XCD), %s%8zu B: PRODUCT stores only", nblk, nblk / 16 / 8, separate ? "one hipMalloc per column, " : "one allocation, column skew ", skew);
                     if (ctx[1]) report(name, timeit(reps, [&](int i, hipStream_t s) { product(1, i, s); }));
-                    snprintf(name, sizeof name, "n = %8u blocks (%5u groups per XCD), column skew %8zu B: round-sliced emulation", nblk, nblk / 16 / 8, skew);
+                    snprintf(name, sizeof name, "n = %8u blocks (%5u groups per XCD), %s%8zu B: PRODUCT, nontemporal stores", nblk, nblk / 16 / 8, separate ? "one hipMalloc per column, " : "one allocation, column skew ", skew);
+                    if (ctx[2]) report(name, timeit(reps, [&](int i, hipStream_t s) { product(2, i, s); }));
+                    snprintf(name, sizeof name, "n = %8u blocks (%5u groups per XCD), %s%8zu B: round-sliced emulation", nblk, nblk / 16 / 8, separate ? "one hipMalloc per column, " : "one allocation, column skew ", skew);
                     report(name, timeit(reps, [&](int i, hipStream_t s) { hipLaunchKernelGGL(k_rounds, dim3(nblk / 16), dim3(64), 0, s, cols_of(i, 0), nblk); }));
                     snprintf(name, sizeof name, "n = %8u blocks: linear 4 KiB fill, sc1", nblk);
                     report(name, timeit(reps, [&](int i, hipStream_t s) { hipLaunchKernelGGL(k_fill, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, s, buf[i % NBUF], bytes, 2); }));
@@ -278,6 +293,7 @@ int main(int argc, char **argv) {
         report("linear 4 KiB fill, nontemporal", timeit(reps, [&](int i, hipStream_t s) { hipLaunchKernelGGL(k_fill, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, s, buf[i % NBUF], bytes, 1); }));
         if (ctx[0]) report("PRODUCT encrypt_kernel<packed, per-block keys + key witness> (store_mode 2)", timeit(reps, [&](int i, hipStream_t s) { product(0, i, s); }));
         if (ctx[1]) report("PRODUCT stores only (store_mode 5: same schedule, geometry, residency; nothing computed)", timeit(reps, [&](int i, hipStream_t s) { product(1, i, s); }));
+        if (ctx[2]) report("PRODUCT with nontemporal stores (store_mode 1)", timeit(reps, [&](int i, hipStream_t s) { product(2, i, s); }));
         report("round-sliced emulation (unitbench k_rounds), 1 wave x 16 blocks, XCD-contiguous", timeit(reps, [&](int i, hipStream_t s) { hipLaunchKernelGGL(k_rounds, dim3(nblk / 16), dim3(64), 0, s, cols_of(i, 0), nblk); }));
         // fill order alone (no seeds): what the 7-stream panel order costs against the linear fill
         for (int xcd : {0, 1})
