@@ -579,7 +579,7 @@ def main():
                                     ("c1_dense", 1 << 16, False, pkg.LAYOUT_DENSE),
                                     ("c2_dense", 1 << 20, True, pkg.LAYOUT_DENSE)):
             try:
-                r = Runner(pkg, ctx, torch, nn, xpbk, lay, xpbk, SEED + 7)
+                r = Runner(pkg, ctx, torch, nn, xpbk, lay, xpbk, SEED + 7, arena=use_arena)
                 steps = 50 if nn <= (1 << 16) else 12
                 r.prepare(steps, 3, not a.no_graph)
                 runs = sorted((r.timed() for _ in range(3)), key=lambda t: t[1])
@@ -588,6 +588,7 @@ def main():
                                 "achieved_GBps": r.bytes_per_block * nn / (ms * 1e-3) / 1e9,
                                 "frac": r.bytes_per_block * nn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                 "written_GBps": r.out_bytes_per_step / (ms * 1e-3) / 1e9}
+                r.close()
                 del r
                 torch.cuda.empty_cache()
             except Exception as e:  # keep the headline even if an extra fails
@@ -697,7 +698,7 @@ def main():
                 torch.cuda.empty_cache()
                 n3 = 1 << (a.c3_log2_blocks or 21)
                 dog.arm("c3 generation", 120.0)
-                r3 = Runner(pkg, ctx, torch, n3, False, layout, False, SEED + 11 + rank)
+                r3 = Runner(pkg, ctx, torch, n3, False, layout, False, SEED + 11 + rank, arena=use_arena)
                 steps3 = 10
                 w3, ms3, _ = r3.run(steps3, 2, not a.no_graph, barrier)
                 t3 = torch.tensor([w3, ms3], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
@@ -713,6 +714,7 @@ def main():
                                   "gather_seconds": dt3, "gather_GBps_into_root": (world - 1) * n3 * sum(strides) / dt3 / 1e9,
                                   "gather_path": pkg.sharding.last_gather_path,
                                   "note": "generation and gather timed separately; the gather is bound by the root's xGMI ingest"}
+                r3.close()
                 del r3
             except Exception as e:
                 dog.disarm()

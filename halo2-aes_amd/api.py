@@ -561,13 +561,17 @@ class Context:
         return out
 
     def assemble_advice(self, k: int, n_sets: int, witness: Witness, key_witness: KeyWitness | None, n_blocks: int,
-                        layout: int = K.LAYOUT_PACKED, as_fr: bool = False):
+                        layout: int = K.LAYOUT_PACKED, as_fr: bool = False, out=None):
         """All advice columns of a FixedAes128Config<K, n_sets> circuit as the prover holds them:
-        [(3*n_sets+1), 2^k] bytes, or [(3*n_sets+1), 2^k, 32] Fr cells with as_fr."""
+        [(3*n_sets+1), 2^k] bytes, or [(3*n_sets+1), 2^k, 32] Fr cells with as_fr (into `out` when given)."""
         torch = self._torch()
         ncol = 3 * n_sets + 1
         shape = (ncol, 1 << k, 32) if as_fr else (ncol, 1 << k)
-        out = torch.empty(shape, dtype=torch.uint8, device=self._dev())
+        if out is None:
+            out = torch.empty(shape, dtype=torch.uint8, device=self._dev())
+        elif tuple(out.shape) != shape:
+            raise ValueError("out must have shape %r" % (shape,))
+        self._u8(out, "out")
         ks = KeySlab(*[t.data_ptr() for t in key_witness[:4]]) if key_witness is not None else None
         rc = self._lib.aesw_assemble_advice_device(
             self._h, k, n_sets, n_blocks, layout, witness.x.data_ptr(), witness.y.data_ptr(), witness.z.data_ptr(),

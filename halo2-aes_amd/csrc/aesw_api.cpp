@@ -38,6 +38,9 @@ struct aesw_ctx {
     int key_nt = 1;  // store flavour of key_kernel (one contiguous flush per column at the end): nontemporal 4-9 % ahead of sc1 (tools/keysweep.py)
     int fr_geo = 1;  // geometry of expand_fr: 1 = one-shot 4 KiB workgroups, LUT gathered from global memory: 7.3 TB/s with nontemporal stores
                      // against 5.2 for 0 = striding workgroups + LDS LUT and 5.9 for 2 = one-shot 16 KiB + LDS LUT (tools/frsweep.py)
+    int asm_geo = 0;  // geometry of the Fr form of assemble: 0 = striding workgroups (default: 5.6 TB/s for K=20, N=5), 1 = division-free one-shot
+                      // workgroups on a (chunk, segment, column) grid (round 3: byte-exact, 5.2 TB/s -- a piece is a chain of three dependent loads
+                      // (index table, slab byte, LUT) and a one-shot workgroup has nothing else in flight: latency x residency bounds it, not divisions)
     int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)
     int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
     uint32_t xcd_remap = 1;  // xcd_group() mode: 0 dispatch order, 1 one contiguous eighth of the groups per XCD (+3-4 % at 2^20 blocks over 0, tools/sweep.py xcd), C >= 2 turns of C groups
@@ -419,6 +422,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "key_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->key_nt = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "fr_geometry")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_geo = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "fr_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_nt = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "assemble_geometry")) { if (value < 0 || value > 1) return AESW_ERR_INVALID_ARG; ctx->asm_geo = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { if (value < 0 || value > (1 << 24)) return AESW_ERR_INVALID_ARG; ctx->xcd_remap = (uint32_t)value; return AESW_OK; }
     if (!std::strcmp(name, "lds_pad")) { if (value < 0 || value > 120 * 1024) return AESW_ERR_INVALID_ARG; ctx->lds_pad = value; return AESW_OK; }
@@ -449,6 +453,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "key_store_mode")) { *value = ctx->key_nt; return AESW_OK; }
     if (!std::strcmp(name, "fr_store_mode")) { *value = ctx->fr_nt; return AESW_OK; }
     if (!std::strcmp(name, "fr_geometry")) { *value = ctx->fr_geo; return AESW_OK; }
+    if (!std::strcmp(name, "assemble_geometry")) { *value = ctx->asm_geo; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { *value = ctx->grid_cap; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { *value = ctx->xcd_remap; return AESW_OK; }
     if (!std::strcmp(name, "lds_pad")) { *value = ctx->lds_pad; return AESW_OK; }
@@ -599,6 +604,7 @@ int fill_assemble_params(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_
     p->sx = aesw_column_stride(layout, 0); p->sy = aesw_column_stride(layout, 1); p->sz = aesw_column_stride(layout, 2);
     p->kxs = aesw_key_column_stride(layout, 0); p->kys = aesw_key_column_stride(layout, 1); p->kzs = aesw_key_column_stride(layout, 2);
     p->packed = layout == AESW_LAYOUT_PACKED;
+    p->geometry = ctx->asm_geo;
     return AESW_OK;
 }
 uint64_t now_ns() {
@@ -698,7 +704,7 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
         out->x = at(0); out->y = at(1); out->z = at(2); out->ct = at(3);
         out->key.w = at(4); out->key.kx = at(5); out->key.ky = at(6); out->key.kz = at(7);
     };
-    int probe = ctx->arena_probe < 0 ? (n >= ((uint64_t)1 << 18) ? 8 : 0) : ctx->arena_probe;
+    int probe = ctx->arena_probe < 0 ? (n >= ((uint64_t)1 << 16) ? 8 : 0) : ctx->arena_probe;
     if (probe == 0) {
         // hipMalloc returns memory aligned to the allocation granule only: over-allocate by one alignment unit
         uint8_t *raw = nullptr;
@@ -766,7 +772,8 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
         for (int c : order)
             if (size[size_of7[c]]) units.push_back({c});
     }
-    const int passes = 2;
+    // two timed passes of a 2^20-block set; proportionally more for smaller batches (short launches time noisily)
+    const int passes = n >= ((uint64_t)1 << 20) ? 2 : (int)std::min<uint64_t>(32, (((uint64_t)1 << 21) + n - 1) / n);
     uint32_t total_cands = 0;
     float last_probe = 0.f, last_fill = 1.f;
     uint8_t *ct_ptr = nullptr;

@@ -58,6 +58,8 @@ struct AssembleParams {
     uint32_t col_first, col_count;       // the advice columns to write (out holds col_count columns)
     uint32_t sx, sy, sz, kxs, kys, kzs;  // bytes per block / per key
     int packed;
+    int geometry;         // Fr cells: 1 = one-shot 4 KiB workgroups on a (chunk, segment, column) grid, 0 = striding workgroups
+    uint64_t cap0, capn;  // blocks per column set (set 0 / the others): filled by the launcher
 };
 hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int store_mode, hipStream_t s);
 // placement probe of aesw_columns_alloc: columns x, y, z, w, kx, ky, kz (null = absent) of n blocks

@@ -693,7 +693,60 @@ __device__ __forceinline__ uint32_t advice_cell(const AssembleParams &a, uint32_
     return idx >= 0 ? sc[b * stride + idx] : 0u;
 }
 
-// (A one-shot geometry like expand_fr's was tried for this kernel in round 2 and is 9x SLOWER: a piece here is a chain of
+// Round 3: the Fr form of the columns as ONE-SHOT workgroups without a division.  A column of 2^k rows
+// is cut into a head (rows [0, base): the 400 key rows of set 0's columns, empty elsewhere) and segments of AES_ROWS rows
+// behind it -- exactly the blocks of aes_callable's placement, then never-assigned rows.  Grid: x = 4 KiB chunk of a
+// segment's AES_ROWS x 32 B (11 of them, the last one partial), y = segment, z = column; a thread writes one 16-byte half
+// cell with one nontemporal store and exits (the geometry that takes expand_fr to 7.3 TB/s).  Row, block and set follow
+// from the grid indices by shifts, compares and one multiplication by a constant; the capacities come from the host.
+// Measured (tools/asm_geo.py, K = 20, N = 5, 512 MiB): 102.7 us = 5.2 TB/s against 96.6 us = 5.6 TB/s for the striding kernel
+// below, byte for byte the same output.  So the divisions were not what held the one-shot form back in round 2: a piece is a
+// chain of three dependent loads (packed-index table -> slab byte -> LUT), a one-shot workgroup has nothing else in flight,
+// and 2 048 resident workgroups x 4 KiB / (that chain's latency) is the rate; expand_fr, whose chain is two loads long, reaches
+// 7.3 TB/s in the same geometry.  Kept as option "assemble_geometry" 1, tested; the striding kernel stays the default.
+template <int NT>
+__global__ void __launch_bounds__(256) assemble_fr_oneshot_kernel(const AssembleParams a) {
+    const uint32_t piece = blockIdx.x * 256 + threadIdx.x;  // 16-byte piece of the segment: 2 per row
+    const uint32_t r = piece >> 1;                           // row inside the segment
+    if (r >= AES_ROWS) return;
+    const uint32_t col = a.col_first + blockIdx.z, seg = blockIdx.y;
+    const uint32_t n_adv = 3 * a.n_sets;
+    const bool words = col == n_adv;
+    const uint32_t set = col / 3, c = col - 3 * set;
+    const uint64_t rows = (uint64_t)1 << a.k;
+    const uint32_t base = (!words && set == 0) ? KEY_ROWS : 0;
+    uint64_t row;
+    uint32_t v = 0;
+    if (seg == 0) {  // head: key rows of set 0
+        if (r >= base) return;
+        row = r;
+        const uint8_t *kc = c == 0 ? a.kx : c == 1 ? a.ky : a.kz;
+        if (kc) {
+            const int idx = a.packed ? a.pidx[3 * AES_ROWS + c * KEY_ROWS + r] : (int)r;
+            if (idx >= 0) v = kc[idx];
+        }
+    } else {
+        const uint64_t bi = seg - 1;
+        row = base + bi * AES_ROWS + r;
+        if (row >= rows) return;
+        if (words) {
+            if (row < WORDS_ROWS && a.kw) v = a.kw[row];
+        } else if (bi < (set == 0 ? a.cap0 : a.capn)) {
+            const uint64_t b = (set == 0 ? 0 : a.cap0 + (uint64_t)(set - 1) * a.capn) + bi;
+            if (b < a.n_blocks) {
+                const uint8_t *sc = c == 0 ? a.x : c == 1 ? a.y : a.z;
+                const uint32_t stride = c == 0 ? a.sx : c == 1 ? a.sy : a.sz;
+                const int idx = a.packed ? a.pidx[c * AES_ROWS + r] : (int)r;
+                if (idx >= 0) v = sc[b * stride + idx];
+            }
+        }
+    }
+    const u32x4 *lut = reinterpret_cast<const u32x4 *>(a.fr_lut);  // 8 KiB, L1 / L2 resident
+    u32x4 *out = reinterpret_cast<u32x4 *>(a.out) + (((uint64_t)blockIdx.z << a.k) + row) * 2 + (piece & 1);
+    gstore<NT>(out, lut[v * 2 + (piece & 1)]);
+}
+
+// (A one-shot geometry like expand_fr's was tried for the cell-indexed form below in round 2 and is 9x SLOWER: a piece here is a chain of
 // three dependent loads -- packed-index table, slab byte, LUT -- behind 64-bit divisions, and a thread with a single piece
 // has nothing to overlap them with; the striding loop below lets the compiler keep several pieces in flight per lane.)
 template <bool AS_FR, int NT>
@@ -947,7 +1000,23 @@ hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t
     return hipGetLastError();
 }
 
-hipError_t launch_assemble(const AssembleParams &p, bool as_fr, int nt, hipStream_t s) {
+hipError_t launch_assemble(const AssembleParams &p0, bool as_fr, int nt, hipStream_t s) {
+    AssembleParams p = p0;
+    {   // capacities of aes_callable (src/aes128.rs:303-325): computed here so that no kernel divides
+        const uint64_t rows = (uint64_t)1 << p.k;
+        p.cap0 = rows >= 1760 ? (rows - 1760) / AES_ROWS : 0;
+        p.capn = rows / AES_ROWS;
+    }
+    if (as_fr && p.geometry == 1 && p.col_count > 0) {
+        const uint64_t rows = (uint64_t)1 << p.k;
+        const uint64_t segs = 1 + (rows + AES_ROWS - 1) / AES_ROWS;  // head + blocks (+ the tail, clipped in the kernel)
+        if (segs > 65535 || p.col_count > 65535) return hipErrorInvalidValue;
+        const dim3 grid((AES_ROWS * 2 + 255) / 256, (unsigned)segs, p.col_count);
+        if (nt == 2) hipLaunchKernelGGL((assemble_fr_oneshot_kernel<2>), grid, dim3(256), 0, s, p);
+        else if (nt == 1) hipLaunchKernelGGL((assemble_fr_oneshot_kernel<1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((assemble_fr_oneshot_kernel<0>), grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     const uint64_t cells = (uint64_t)p.col_count << p.k;
     uint64_t blocks = ((as_fr ? cells * 2 : cells / 4) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

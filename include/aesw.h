@@ -219,7 +219,7 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
  * stable for the life of an allocation, while a linear fill of the same buffers took 587 us on both.  The property
  * belongs to the combination of columns (256 MiB tiles that all look fast in isolation combine into slow sets) and no
  * virtual-address rule predicts it, so the arena is chosen by measurement, one column at a time, largest first: up to
- * "arena_probe" candidate backings per column (default 8 for batches of at least 2^18 blocks; 0 = off: one hipMalloc,
+ * "arena_probe" candidate backings per unit (default 8 for batches of at least 2^16 blocks; 0 = off: one hipMalloc,
  * columns on 2^arena_align_log2-byte boundaries, default 2 MiB) are built with the virtual-memory API from physical
  * chunks of 2 ... 32 MiB; a store-only emulation of the kernel's pattern over the columns placed so far plus the
  * candidate is timed against a linear fill of the same bytes; the first candidate whose pattern runs as fast as its
@@ -353,8 +353,10 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * the block groups per XCD (default), C >= 2 = the XCDs take turns in chunks of C groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
  * pipeline, default 2^15), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB
- * workgroups: the default, 2 one-shot 16 KiB), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto), "arena_probe" (candidate backings
- * aesw_columns_alloc measures, -1 = auto: 8 for batches of at least 2^18 blocks, 0 = none: one hipMalloc).
+ * workgroups: the default, 2 one-shot 16 KiB), "assemble_geometry" (Fr form of aesw_assemble_advice_*: 0 striding workgroups: the default,
+ * 1 division-free one-shot workgroups on a (chunk, segment, column) grid), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto), "arena_probe" (candidate backings
+ * aesw_columns_alloc measures per unit, -1 = auto: 8 for batches of at least 2^16 blocks, 0 = none: one hipMalloc), "arena_unit" (what a candidate
+ * backs: 0 = the whole set of columns in one range, the default; 1 = one column, placed greedily, largest first).
  * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
  * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied).
  * Unknown -> INVALID_ARG */

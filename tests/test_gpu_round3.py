@@ -19,7 +19,7 @@ def test_arena_columns_hold_a_byte_exact_witness(ctx, pkg, oracle, layout_name):
     rng = np.random.default_rng(31)
     n = 3000 + 17
     pt, keys = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, (n, 16), dtype=np.uint8)
-    assert ctx.get_option("arena_probe") == -1  # auto: no probing for a batch this small, one hipMalloc
+    assert ctx.get_option("arena_probe") == -1  # auto: no probing for a batch this small (< 2^16 blocks), one hipMalloc
     for align_log2, expect in ((0, 2 << 20), (12, 1 << 12), (21, 2 << 20)):  # auto = 2 MiB
         ctx.set_option("arena_align_log2", align_log2)
         assert ctx.get_option("arena_align_log2") == align_log2
@@ -63,7 +63,7 @@ def test_probed_arena_holds_a_byte_exact_witness(ctx, pkg, oracle):
         ctx.set_option("arena_probe", probe)
         w = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
         info = ctx.last_arena
-        assert 7 <= info["candidates"] <= 7 * (8 if probe < 0 else probe)  # seven probed columns, 1 .. arena_probe candidates each
+        assert 1 <= info["candidates"] <= (8 if probe < 0 else probe)  # whole-set candidates (arena_unit 0)
         assert info["probe_us"] > 0 and info["fill_us"] > 0 and info["probe_us"] < 3 * info["fill_us"]
         for t in (w.x, w.y, w.z, w.key.w, w.key.kx, w.key.ky, w.key.kz):
             assert t.data_ptr() % (2 << 20) == 0
@@ -75,6 +75,18 @@ def test_probed_arena_holds_a_byte_exact_witness(ctx, pkg, oracle):
         for c in ("w", "kx", "ky", "kz"):
             assert np.array_equal(getattr(got.key, c).cpu().numpy(), getattr(k, c)), c
         ctx.free_columns(w)
+    # one column per candidate, placed greedily
+    ctx.set_option("arena_probe", 2)
+    ctx.set_option("arena_unit", 1)
+    w = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
+    assert 7 <= ctx.last_arena["candidates"] <= 14
+    got = ctx.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, want_ct=True, key_slab=True)
+    torch.cuda.synchronize()
+    for c in "xyz":
+        assert np.array_equal(getattr(got, c).cpu().numpy(), getattr(e, c)), c
+    assert np.array_equal(got.ct.cpu().numpy(), e.ct) and np.array_equal(got.key.kz.cpu().numpy(), k.kz)
+    ctx.free_columns(w)
+    ctx.set_option("arena_unit", 0)
     ctx.set_option("arena_probe", -1)
 
 
@@ -84,7 +96,7 @@ def test_every_settable_option_reads_back(pkg):
         pytest.skip("no GPU")
     c = pkg.Context(0)
     for name, value in (("waves_shared", 2), ("waves_pbk", 3), ("store_mode", 1), ("key_store_mode", 2), ("fr_store_mode", 0),
-                        ("fr_geometry", 2), ("grid_cap", 512), ("xcd_remap", 0), ("xcd_remap", 64), ("lds_pad", 4096), ("arena_align_log2", 16), ("arena_probe", 3),
+                        ("fr_geometry", 2), ("grid_cap", 512), ("xcd_remap", 0), ("xcd_remap", 64), ("lds_pad", 4096), ("arena_align_log2", 16), ("arena_probe", 3), ("arena_unit", 1),
                         ("chunk_blocks", 4096)):
         c.set_option(name, value)
         assert c.get_option(name) == value, name
@@ -135,3 +147,28 @@ def test_scheduled_key_capture_on_a_foreign_stream_is_refused(pkg, oracle):
     for col in "xyz":
         assert np.array_equal(getattr(out, col).cpu().numpy(), getattr(e, col)), col
     c.close()
+
+
+def test_assemble_oneshot_geometry_equals_the_striding_kernel_and_synthesize(ctx, pkg, oracle):
+    """assemble_geometry 1 (round 3: one-shot workgroups on a (chunk, segment, column) grid, no division in the kernel) writes
+    the same Fr columns as the striding kernel, and both equal the restated synthesize() of a K = 12, N = 2 circuit with a
+    partly filled last set, never-assigned rows and the words column included."""
+    import torch
+    k, n_sets = 12, 2
+    cap = pkg.block_capacity(k, n_sets)
+    n = cap - 1  # one empty block slot at the end of set 1
+    rng = np.random.default_rng(91)
+    key, pts = rng.integers(0, 256, 16, dtype=np.uint8), rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    kw = ctx.schedule_key(torch.from_numpy(key).cuda(), layout=pkg.LAYOUT_PACKED, key_slab=True)
+    wit = ctx.encrypt_witness(torch.from_numpy(pts).cuda(), None, layout=pkg.LAYOUT_PACKED)
+    outs = []
+    for geo in (0, 1):
+        ctx.set_option("assemble_geometry", geo)
+        outs.append(ctx.assemble_advice(k, n_sets, wit, kw, n, layout=pkg.LAYOUT_PACKED, as_fr=True).cpu().numpy())
+    ctx.set_option("assemble_geometry", 0)
+    assert np.array_equal(outs[0], outs[1])
+    fr_mod = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    lut = np.stack([np.frombuffer(((v << 256) % fr_mod).to_bytes(32, "little"), np.uint8) for v in range(256)])
+    with oracle.circuit(k, n_sets, key, pts, record_copies=False) as c:
+        for col in range(3 * n_sets + 1):
+            assert np.array_equal(outs[1][col], lut[c.advice(col)]), col

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""assemble_kernel as Fr cells: striding workgroups (assemble_geometry 0) vs the division-free one-shot grid (1, round 3).
+K = 20, N = 5 (16 columns x 2^20 cells x 32 B = 512 MiB), full capacity; both outputs compared byte for byte."""
+import statistics
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+import __graft_entry__ as ge  # noqa: E402
+ge.build()
+pkg = ge.load_package()
+k, n_sets = 20, 5
+ctx = pkg.Context(0)
+nn = pkg.block_capacity(k, n_sets)
+pt = torch.randint(0, 256, (nn, 16), dtype=torch.uint8, device="cuda")
+key = torch.randint(0, 256, (16,), dtype=torch.uint8, device="cuda")
+kw = ctx.schedule_key(key, layout=pkg.LAYOUT_PACKED, key_slab=True)
+wit = ctx.encrypt_witness(pt, None, layout=pkg.LAYOUT_PACKED)
+outs = {}
+res = {0: [], 1: []}
+for rnd in range(5):
+    for geo in (0, 1):
+        ctx.set_option("assemble_geometry", geo)
+        out = ctx.assemble_advice(k, n_sets, wit, kw, nn, layout=pkg.LAYOUT_PACKED, as_fr=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            out = ctx.assemble_advice(k, n_sets, wit, kw, nn, layout=pkg.LAYOUT_PACKED, as_fr=True, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        res[geo].append(e0.elapsed_time(e1) / 10 * 1e3)
+        outs[geo] = out
+assert torch.equal(outs[0], outs[1]), "the two geometries disagree"
+nbytes = outs[0].numel()
+for geo in (0, 1):
+    med = statistics.median(res[geo])
+    print("assemble_geometry %d: %8.2f us per %d MiB  -> %6.0f GB/s written" % (geo, med, nbytes >> 20, nbytes / med / 1e3))

@@ -43,7 +43,17 @@ if kt:
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[-100:]]
     summary["timed_region_us"] = {"n": len(d), "mean": statistics.mean(d), "median": statistics.median(d), "min": min(d), "max": max(d)}
     summary["lds_block_bytes"] = rows[-1].get("LDS_Block_Size")
-    summary["vgpr"] = rows[-1].get("VGPR_Count")
+    # the kernel trace's VGPR_Count column is the ARCHITECTURAL VGPR allocation of the dispatch (104 for the headline
+    # kernel since round 1); the code object's unified register count (.vgpr_count: VGPRs + AGPRs, what bounds residency)
+    # is tracked in profiles/isa_resources.json by tests/test_isa_lint.py and copied in below
+    summary["vgpr_count_column_of_kernel_trace"] = rows[-1].get("VGPR_Count")
+    try:
+        import re
+        isa = json.loads((ROOT / "profiles" / "isa_resources.json").read_text())
+        short = re.sub(r"\(.*\)$", "", summary.get("kernel", "").replace("void ", "").replace("aesw::", "")).replace(", ", ",")
+        summary["code_object"] = isa.get(short)
+    except Exception:
+        pass
     summary["sgpr"] = rows[-1].get("SGPR_Count")
 
 
