@@ -47,7 +47,8 @@ struct aesw_ctx {
     int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
     int arena_align_log2 = 0;  // aesw_columns_alloc: column alignment (0 = auto: 2 MiB)
     int arena_probe = -1;      // candidate backings aesw_columns_alloc measures per unit (-1 = auto, 0 = none: one hipMalloc)
-    int arena_unit = 0;        // what a candidate is: 0 = the whole set of columns in one range, 1 = one column (greedy, largest first)
+    int arena_unit = 2;        // what a candidate is: 0 = the whole set of columns in one range, 1 = one column (greedy, largest first),
+                               // 2 = whole sets first, columns if no set candidate runs the pattern as fast as its fill (default)
     struct ArenaRange { void *p; size_t bytes; bool vmm; };  // vmm: built with the virtual-memory API (freed by unmap), else hipMalloc
     struct ArenaRec { void *key; std::vector<ArenaRange> ranges; };
     std::vector<ArenaRec> vmm_arenas;  // arenas built with the virtual-memory API (one range per column; freed by unmap, not hipFree)
@@ -428,7 +429,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "lds_pad")) { if (value < 0 || value > 120 * 1024) return AESW_ERR_INVALID_ARG; ctx->lds_pad = value; return AESW_OK; }
     if (!std::strcmp(name, "arena_align_log2")) { if (value != 0 && (value < 7 || value > 32)) return AESW_ERR_INVALID_ARG; ctx->arena_align_log2 = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "arena_probe")) { if (value < -1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->arena_probe = (int)value; return AESW_OK; }
-    if (!std::strcmp(name, "arena_unit")) { if (value < 0 || value > 1) return AESW_ERR_INVALID_ARG; ctx->arena_unit = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "arena_unit")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->arena_unit = (int)value; return AESW_OK; }
 #ifdef AESW_TRACE
     if (!std::strcmp(name, "trace_ptr")) { ctx->trace = reinterpret_cast<uint64_t *>(value); return AESW_OK; }
 #endif
@@ -762,78 +763,106 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     for (int c = 0; c < 7; ++c) pp.stride[c] = strides7[c];
     pp.n = n;
     pp.xcd_mode = ctx->xcd_remap;
-    // units: lists of probe columns placed together
-    std::vector<std::vector<int>> units;
-    if (ctx->arena_unit == 0) {
-        units.push_back({0, 1, 2, 3, 4, 5, 6});
-    } else {
-        int order[7] = {0, 1, 2, 3, 4, 5, 6};
-        std::sort(order, order + 7, [&](int a, int b) { return size[size_of7[a]] > size[size_of7[b]]; });
-        for (int c : order)
-            if (size[size_of7[c]]) units.push_back({c});
-    }
     // two timed passes of a 2^20-block set; proportionally more for smaller batches (short launches time noisily)
     const int passes = n >= ((uint64_t)1 << 20) ? 2 : (int)std::min<uint64_t>(32, (((uint64_t)1 << 21) + n - 1) / n);
     uint32_t total_cands = 0;
-    float last_probe = 0.f, last_fill = 1.f;
-    uint8_t *ct_ptr = nullptr;
-    for (size_t ui = 0; ui < units.size(); ++ui) {
-        const std::vector<int> &cols = units[ui];
-        // layout of the unit: its columns one after the other on 2 MiB boundaries (the ciphertext rides with a whole-set unit)
-        size_t uoff[8], ubytes = 0;
-        for (int c : cols) { uoff[c] = ubytes; ubytes += round2m(size[size_of7[c]]); }
-        const bool with_ct_here = ctx->arena_unit == 0 && size[3];
-        if (with_ct_here) { uoff[7] = ubytes; ubytes += round2m(size[3]); }
-        if (!ubytes) continue;
-        Range best{nullptr, 0, false};
-        float best_ratio = 0.f, best_probe = 0.f, best_fill = 1.f;
-        for (int k = 0; k < probe; ++k) {
-            Range r{nullptr, 0, false};
-            const int rc = build(k + (int)ui, ubytes, &r);
-            if (rc != AESW_OK) {
-                if (!best.p) return rc;  // not even one candidate for this unit fits
-                break;                   // memory is getting short: choose among what we have
-            }
-            losers.push_back(r);  // owned by ~Cleanup unless chosen below
-            ++total_cands;
-            for (int c : cols) pp.col[c] = size[size_of7[c]] ? reinterpret_cast<uint8_t *>(r.p) + uoff[c] : nullptr;
-            HIP_TRY(ctx, launch_probe(pp, false, nullptr));  // first touch + warm-up, untimed
-            HIP_TRY(ctx, hipEventRecord(e0, nullptr));
-            for (int i = 0; i < passes; ++i) HIP_TRY(ctx, launch_probe(pp, false, nullptr));
-            HIP_TRY(ctx, hipEventRecord(e1, nullptr));
-            for (int i = 0; i < passes; ++i) HIP_TRY(ctx, launch_probe(pp, true, nullptr));
-            HIP_TRY(ctx, hipEventRecord(e2, nullptr));
-            HIP_TRY(ctx, hipEventSynchronize(e2));
-            float f = 0, l = 0;
-            HIP_TRY(ctx, hipEventElapsedTime(&f, e0, e1));
-            HIP_TRY(ctx, hipEventElapsedTime(&l, e1, e2));
-            const float ratio = f / l;
-            if (!best.p || ratio < best_ratio) { best = r; best_ratio = ratio; best_probe = f * 1e3f / passes; best_fill = l * 1e3f / passes; }
-            if (ratio <= 1.0f) break;  // the many-front pattern as fast as a linear fill: as good as it gets
+    struct Placement {
+        std::vector<Range> ranges;
+        uint8_t *col[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        uint8_t *ct = nullptr;
+        float probe_us = 0.f, fill_us = 1.f;
+        int rc = AESW_OK;
+    };
+    // one search: unit_mode 0 = whole-set candidates, 1 = one column at a time (greedy, largest first)
+    auto search = [&](int unit_mode) -> Placement {
+        Placement pl;
+        ProbeParams q = pp;
+        for (int c = 0; c < 7; ++c) q.col[c] = nullptr;
+        std::vector<std::vector<int>> units;
+        if (unit_mode == 0) {
+            units.push_back({0, 1, 2, 3, 4, 5, 6});
+        } else {
+            int order[7] = {0, 1, 2, 3, 4, 5, 6};
+            std::sort(order, order + 7, [&](int a, int b) { return size[size_of7[a]] > size[size_of7[b]]; });
+            for (int c : order)
+                if (size[size_of7[c]]) units.push_back({c});
         }
-        for (size_t i = 0; i < losers.size(); ++i)
-            if (losers[i].p == best.p) { losers.erase(losers.begin() + (long)i); break; }
-        rec.ranges.push_back(best);
-        for (int c : cols) pp.col[c] = size[size_of7[c]] ? reinterpret_cast<uint8_t *>(best.p) + uoff[c] : nullptr;
-        if (with_ct_here) ct_ptr = reinterpret_cast<uint8_t *>(best.p) + uoff[7];
-        last_probe = best_probe;
-        last_fill = best_fill;
+        auto fail = [&](int rc) { for (auto &r : pl.ranges) losers.push_back(r); pl.ranges.clear(); pl.rc = rc; return pl; };
+        auto hip = [&](hipError_t e, const char *what) { return e == hipSuccess ? AESW_OK : fail_hip(ctx, e, what); };
+        for (size_t ui = 0; ui < units.size(); ++ui) {
+            const std::vector<int> &cols = units[ui];
+            // layout of the unit: its columns one after the other on 2 MiB boundaries (the ciphertext rides with a whole-set unit)
+            size_t uoff[8], ubytes = 0;
+            for (int c : cols) { uoff[c] = ubytes; ubytes += round2m(size[size_of7[c]]); }
+            const bool with_ct_here = unit_mode == 0 && size[3];
+            if (with_ct_here) { uoff[7] = ubytes; ubytes += round2m(size[3]); }
+            if (!ubytes) continue;
+            Range best{nullptr, 0, false};
+            float best_probe = 0.f, best_fill = 1.f;
+            float ref_fill = 0.f;  // the fastest linear fill seen for this unit: one slow fill sample must not make a candidate look good
+            for (int k = 0; k < probe; ++k) {
+                Range r{nullptr, 0, false};
+                int rc = build(k + (int)ui, ubytes, &r);
+                if (rc != AESW_OK) {
+                    if (!best.p) return fail(rc);  // not even one candidate for this unit fits
+                    break;                         // memory is getting short: choose among what we have
+                }
+                losers.push_back(r);  // owned by ~Cleanup unless chosen below
+                ++total_cands;
+                for (int c : cols) q.col[c] = size[size_of7[c]] ? reinterpret_cast<uint8_t *>(r.p) + uoff[c] : nullptr;
+                rc = hip(launch_probe(q, false, nullptr), "probe launch");  // first touch + warm-up, untimed
+                if (rc == AESW_OK) rc = hip(hipEventRecord(e0, nullptr), "hipEventRecord");
+                for (int i = 0; i < passes && rc == AESW_OK; ++i) rc = hip(launch_probe(q, false, nullptr), "probe launch");
+                if (rc == AESW_OK) rc = hip(hipEventRecord(e1, nullptr), "hipEventRecord");
+                for (int i = 0; i < passes && rc == AESW_OK; ++i) rc = hip(launch_probe(q, true, nullptr), "probe launch");
+                if (rc == AESW_OK) rc = hip(hipEventRecord(e2, nullptr), "hipEventRecord");
+                if (rc == AESW_OK) rc = hip(hipEventSynchronize(e2), "hipEventSynchronize");
+                float f = 0, l = 0;
+                if (rc == AESW_OK) rc = hip(hipEventElapsedTime(&f, e0, e1), "hipEventElapsedTime");
+                if (rc == AESW_OK) rc = hip(hipEventElapsedTime(&l, e1, e2), "hipEventElapsedTime");
+                if (rc != AESW_OK) return fail(rc);
+                if (ref_fill == 0.f || l < ref_fill) ref_fill = l;
+                const float ratio = f / ref_fill;
+                if (!best.p || f < best_probe * passes * 1e-3f) { best = r; best_probe = f * 1e3f / passes; }
+                best_fill = ref_fill * 1e3f / passes;
+                if (ratio <= 1.0f) break;  // the many-front pattern as fast as a linear fill: as good as it gets
+            }
+            for (size_t i = 0; i < losers.size(); ++i)
+                if (losers[i].p == best.p) { losers.erase(losers.begin() + (long)i); break; }
+            pl.ranges.push_back(best);
+            for (int c : cols) q.col[c] = size[size_of7[c]] ? reinterpret_cast<uint8_t *>(best.p) + uoff[c] : nullptr;
+            if (with_ct_here) pl.ct = reinterpret_cast<uint8_t *>(best.p) + uoff[7];
+            pl.probe_us = best_probe;  // after the last unit: the whole set as finally placed
+            pl.fill_us = best_fill;
+        }
+        if (size[3] && !pl.ct) {  // column units: the ciphertext is one small linear stream outside the pattern: any backing
+            Range r{nullptr, 0, false};
+            const int rc = build(1, round2m(size[3]), &r);
+            if (rc != AESW_OK) return fail(rc);
+            pl.ranges.push_back(r);
+            pl.ct = reinterpret_cast<uint8_t *>(r.p);
+        }
+        for (int c = 0; c < 7; ++c) pl.col[c] = q.col[c];
+        return pl;
+    };
+    // "arena_unit" 2 (default): whole-set candidates first; when none of them runs the pattern as fast as its fill, a second
+    // search places the columns one at a time (the whole-set losers stay held meanwhile) and the better of the two is kept
+    Placement pl = search(ctx->arena_unit == 1 ? 1 : 0);
+    if (pl.rc != AESW_OK) return pl.rc;
+    if (ctx->arena_unit == 2 && pl.probe_us > pl.fill_us) {
+        Placement alt = search(1);
+        if (alt.rc == AESW_OK && alt.probe_us / alt.fill_us < pl.probe_us / pl.fill_us) std::swap(pl, alt);
+        for (auto &r : alt.ranges) losers.push_back(r);  // the search that lost (or failed half-way: already handed over)
     }
-    if (size[3] && !ct_ptr) {  // column units: the ciphertext is one small linear stream outside the pattern: any backing
-        Range r{nullptr, 0, false};
-        const int rc = build(1, round2m(size[3]), &r);
-        if (rc != AESW_OK) return rc;
-        rec.ranges.push_back(r);
-        ct_ptr = reinterpret_cast<uint8_t *>(r.p);
-    }
-    out->x = pp.col[0]; out->y = pp.col[1]; out->z = pp.col[2]; out->ct = ct_ptr;
-    out->key.w = pp.col[3]; out->key.kx = pp.col[4]; out->key.ky = pp.col[5]; out->key.kz = pp.col[6];
+    rec.ranges = pl.ranges;
+    out->x = pl.col[0]; out->y = pl.col[1]; out->z = pl.col[2]; out->ct = pl.ct;
+    out->key.w = pl.col[3]; out->key.kx = pl.col[4]; out->key.ky = pl.col[5]; out->key.kz = pl.col[6];
     out->base = out->y;  // the handle aesw_columns_free looks the arena up by (every layout has a y column)
     for (auto &r : rec.ranges) out->bytes += r.bytes;
     out->candidates = total_cands;
     out->chosen = 0;
-    out->probe_us = last_probe;  // the whole set: pattern and fill over all columns as finally placed
-    out->fill_us = last_fill;
+    out->probe_us = pl.probe_us;
+    out->fill_us = pl.fill_us;
     rec.key = out->base;
     ctx->vmm_arenas.push_back(rec);
     done = true;

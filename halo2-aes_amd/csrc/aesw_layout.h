@@ -250,6 +250,11 @@ inline int b128_read_conflict_cost(const int addr[64]) {
 // Deterministic; ~20 ms per layout.  Unused slots all fall into the round's last instruction.
 template <class W>
 inline void build_flush_table(uint32_t *out) {
+    // the descriptor packs a 16-bit LDS offset below P: every valid P must lie below the "unused slot" sentinel, and a
+    // wave's stage of this column must be addressable with 16 bits (the kernel adds the stage base: launch_enc checks the sum)
+    static_assert((uint32_t)(SCHED_BPW * W::GSTRIDE) <= SCHED_INVALID_P, "a wave's global range of this column reaches the unused-slot sentinel");
+    static_assert(SCHED_BPW * W::BYTES <= 65536, "a wave's LDS stage of this column needs more than 16 address bits");
+    static_assert(SCHED_INVALID_P < 0x8000u, "P << 16 must fit the descriptor word's upper half");
     constexpr int NL = SCHED_BPW * W::GSTRIDE / 128;
     int line_round[NL];
     for (int k = 0; k < NL; ++k) line_round[k] = sched_line_round<W>(k);

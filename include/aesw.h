@@ -356,7 +356,8 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * workgroups: the default, 2 one-shot 16 KiB), "assemble_geometry" (Fr form of aesw_assemble_advice_*: 0 striding workgroups: the default,
  * 1 division-free one-shot workgroups on a (chunk, segment, column) grid), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto), "arena_probe" (candidate backings
  * aesw_columns_alloc measures per unit, -1 = auto: 8 for batches of at least 2^16 blocks, 0 = none: one hipMalloc), "arena_unit" (what a candidate
- * backs: 0 = the whole set of columns in one range, the default; 1 = one column, placed greedily, largest first).
+ * backs: 0 = the whole set of columns in one range; 1 = one column, placed greedily, largest first; 2 = whole sets first, then
+ * columns if no whole-set candidate ran the pattern as fast as its fill: the default).
  * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
  * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied).
  * Unknown -> INVALID_ARG */

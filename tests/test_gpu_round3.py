@@ -63,7 +63,7 @@ def test_probed_arena_holds_a_byte_exact_witness(ctx, pkg, oracle):
         ctx.set_option("arena_probe", probe)
         w = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
         info = ctx.last_arena
-        assert 1 <= info["candidates"] <= (8 if probe < 0 else probe)  # whole-set candidates (arena_unit 0)
+        assert 1 <= info["candidates"] <= 8 * (8 if probe < 0 else probe)  # whole-set candidates, then (maybe) seven columns' worth
         assert info["probe_us"] > 0 and info["fill_us"] > 0 and info["probe_us"] < 3 * info["fill_us"]
         for t in (w.x, w.y, w.z, w.key.w, w.key.kx, w.key.ky, w.key.kz):
             assert t.data_ptr() % (2 << 20) == 0
@@ -86,7 +86,7 @@ def test_probed_arena_holds_a_byte_exact_witness(ctx, pkg, oracle):
         assert np.array_equal(getattr(got, c).cpu().numpy(), getattr(e, c)), c
     assert np.array_equal(got.ct.cpu().numpy(), e.ct) and np.array_equal(got.key.kz.cpu().numpy(), k.kz)
     ctx.free_columns(w)
-    ctx.set_option("arena_unit", 0)
+    ctx.set_option("arena_unit", 2)
     ctx.set_option("arena_probe", -1)
 
 

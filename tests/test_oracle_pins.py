@@ -222,3 +222,21 @@ def test_golden_slab_vectors(oracle):
             assert np.array_equal(getattr(k, c), g["%s_%s" % (name, c)])
     assert g["dense_ct"][0].tobytes().hex() == "66e94bd4ef8a2c3b884cfa59ca342b2e"
     assert g["dense_y"][3 * 1360 + 32] == 23   # block 3: S_BOX[0xff] as the reference has it
+    # the VALUES arrays (checked against the device in tests/test_gpu_parity.py) on the CPU too: they are the DENSE arrays
+    # under the selector mask the restated synthesize() derives -- y where the S-box / mul2 / mul3 selector is on, z where the
+    # xor selector is (src/chips/sbox_chip.rs:73-78, gf_mul_chip.rs:75-84, u8_xor_chip.rs:85-95) -- and what the oracle's own
+    # VALUES path returns; a regenerated fixture with a wrong mask fails here without a GPU
+    n = g["pt"].shape[0]
+    for tag, keys in (("values", g["keys"]), ("values_shared", g["keys"][4])):
+        dense = "dense" if tag == "values" else "dense_shared"
+        w = oracle.encrypt_witness(g["pt"], keys, layout=ol.VALUES)
+        assert g[tag + "_x"].size == 0 and w.x.size == 0
+        for ci, c in ((1, "y"), (2, "z")):
+            mask = oracle.values_mask(ci)
+            assert int(mask.sum()) == (448 if ci == 1 else 608)
+            expect = g["%s_%s" % (dense, c)].reshape(n, 1360)[:, mask].reshape(-1)
+            assert np.array_equal(g["%s_%s" % (tag, c)], expect), (tag, c)
+            assert np.array_equal(getattr(w, c), expect), (tag, c)
+    assert np.array_equal(g["values_ct"], g["dense_ct"])
+    for c in ("w", "kx", "ky", "kz", "rk"):  # key slabs of the VALUES layout are the packed ones
+        assert np.array_equal(g["values_" + c], g["packed_" + c]), c

@@ -4,6 +4,7 @@
   malloc    in one hipMalloc arena (aesw_columns_alloc, arena_probe 0)
   set       in a probed arena, candidates = whole sets   (arena_unit 0)
   column    in a probed arena, candidates = single columns, greedy (arena_unit 1)
+  auto      probed arena, the default: whole sets first, columns when no set candidate is fast (arena_unit 2)
 ONE variant per process (who allocates first gets different memory: variants in one process are not comparable); run the
 four back to back on one lease: tools/arena_ab.sh.  bench.py's own Runner (hipGraph of `steps` launches, HIP events).
 usage: arena_ab.py VARIANT [LOG2N] [c2|c1] [arena_probe]      (c1 = one scheduled key, no key witness: BASELINE configs[1])"""
@@ -31,7 +32,7 @@ if variant == "tensors":
     r = bench.Runner(pkg, ctx, torch, n, pbk, L, pbk, 11, arena=False)
 else:
     ctx.set_option("arena_probe", 0 if variant == "malloc" else force)
-    ctx.set_option("arena_unit", 1 if variant == "column" else 0)
+    ctx.set_option("arena_unit", {"column": 1, "set": 0}.get(variant, 2))  # "auto": sets first, columns if no set is fast
     r = bench.Runner(pkg, ctx, torch, n, pbk, L, pbk, 11, arena=True)
 torch.cuda.synchronize()
 setup = time.perf_counter() - t0
