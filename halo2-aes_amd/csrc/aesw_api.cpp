@@ -47,6 +47,7 @@ struct aesw_ctx {
     int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
     int arena_align_log2 = 0;  // aesw_columns_alloc: column alignment (0 = auto: 2 MiB)
     int arena_probe = -1;      // candidate backings aesw_columns_alloc measures per unit (-1 = auto, 0 = none: one hipMalloc)
+    double best_fill_us_per_gb = 0;  // fastest linear fill any arena search of this context has seen (us per 10^9 bytes): the probe's yardstick
     int arena_unit = 2;        // what a candidate is: 0 = the whole set of columns in one range, 1 = one column (greedy, largest first),
                                // 2 = whole sets first, columns if no set candidate runs the pattern as fast as its fill (default)
     struct ArenaRange { void *p; size_t bytes; bool vmm; };  // vmm: built with the virtual-memory API (freed by unmap), else hipMalloc
@@ -743,10 +744,10 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     };
     aesw_ctx::ArenaRec rec{nullptr, {}};
     std::vector<Range> losers;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     bool done = false;
     struct Cleanup {
-        aesw_ctx::ArenaRec &rec; std::vector<Range> &losers; bool &done; hipEvent_t &a, &b, &d;
+        aesw_ctx::ArenaRec &rec; std::vector<Range> &losers; bool &done; hipEvent_t &a, &b, &d, &e;
         ~Cleanup() {
             for (auto &r : losers) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); }
             if (!done)
@@ -754,8 +755,10 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
             if (a) (void)hipEventDestroy(a);
             if (b) (void)hipEventDestroy(b);
             if (d) (void)hipEventDestroy(d);
+            if (e) (void)hipEventDestroy(e);
         }
-    } cleanup{rec, losers, done, e0, e1, e2};
+    } cleanup{rec, losers, done, e0, e1, e2, e3};
+    HIP_TRY(ctx, hipEventCreate(&e3));
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventCreate(&e2));
@@ -814,18 +817,30 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
                 if (rc == AESW_OK) rc = hip(hipEventRecord(e0, nullptr), "hipEventRecord");
                 for (int i = 0; i < passes && rc == AESW_OK; ++i) rc = hip(launch_probe(q, false, nullptr), "probe launch");
                 if (rc == AESW_OK) rc = hip(hipEventRecord(e1, nullptr), "hipEventRecord");
+                if (rc == AESW_OK) rc = hip(launch_probe(q, true, nullptr), "probe launch");  // one untimed fill: the first one after a search's releases runs slow
+                if (rc == AESW_OK) rc = hip(hipEventRecord(e3, nullptr), "hipEventRecord");
                 for (int i = 0; i < passes && rc == AESW_OK; ++i) rc = hip(launch_probe(q, true, nullptr), "probe launch");
                 if (rc == AESW_OK) rc = hip(hipEventRecord(e2, nullptr), "hipEventRecord");
                 if (rc == AESW_OK) rc = hip(hipEventSynchronize(e2), "hipEventSynchronize");
                 float f = 0, l = 0;
                 if (rc == AESW_OK) rc = hip(hipEventElapsedTime(&f, e0, e1), "hipEventElapsedTime");
-                if (rc == AESW_OK) rc = hip(hipEventElapsedTime(&l, e1, e2), "hipEventElapsedTime");
+                if (rc == AESW_OK) rc = hip(hipEventElapsedTime(&l, e3, e2), "hipEventElapsedTime");
                 if (rc != AESW_OK) return fail(rc);
+                {   // the yardstick: the fastest fill seen for this unit, and no slower than the fastest fill per byte this context ever saw
+                    double probed_bytes = 0;
+                    for (int c = 0; c < 7; ++c) if (q.col[c]) probed_bytes += (double)n * q.stride[c];
+                    if (probed_bytes >= 1e9) {  // launches long enough that time per byte is a rate, not ramp and tail
+                        const double per_gb = (double)l * 1e3 / passes / (probed_bytes * 1e-9);
+                        if (ctx->best_fill_us_per_gb == 0 || per_gb < ctx->best_fill_us_per_gb) ctx->best_fill_us_per_gb = per_gb;
+                        const float floor_ms = (float)(ctx->best_fill_us_per_gb * probed_bytes * 1e-9 * passes * 1e-3);
+                        if (l > 1.03f * floor_ms) l = 1.03f * floor_ms;
+                    }
+                }
                 if (ref_fill == 0.f || l < ref_fill) ref_fill = l;
                 const float ratio = f / ref_fill;
                 if (!best.p || f < best_probe * passes * 1e-3f) { best = r; best_probe = f * 1e3f / passes; }
                 best_fill = ref_fill * 1e3f / passes;
-                if (ratio <= 1.0f) break;  // the many-front pattern as fast as a linear fill: as good as it gets
+                if (ratio <= 1.025f) break;  // the many-front pattern as fast as a linear fill (the two levels are 0.98 - 1.02 and >= 1.05): as good as it gets
             }
             for (size_t i = 0; i < losers.size(); ++i)
                 if (losers[i].p == best.p) { losers.erase(losers.begin() + (long)i); break; }
@@ -849,7 +864,7 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     // search places the columns one at a time (the whole-set losers stay held meanwhile) and the better of the two is kept
     Placement pl = search(ctx->arena_unit == 1 ? 1 : 0);
     if (pl.rc != AESW_OK) return pl.rc;
-    if (ctx->arena_unit == 2 && pl.probe_us > pl.fill_us) {
+    if (ctx->arena_unit == 2 && pl.probe_us > 1.025f * pl.fill_us) {
         Placement alt = search(1);
         if (alt.rc == AESW_OK && alt.probe_us / alt.fill_us < pl.probe_us / pl.fill_us) std::swap(pl, alt);
         for (auto &r : alt.ranges) losers.push_back(r);  // the search that lost (or failed half-way: already handed over)
