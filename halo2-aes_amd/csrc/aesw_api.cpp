@@ -29,6 +29,8 @@ struct aesw_ctx {
     bool have_key = false;
     void *key_stream = nullptr;      // the stream the scheduled key's round keys were written on
     hipEvent_t key_ready = nullptr;  // recorded behind the key launch of aesw_schedule_key_device: other streams wait on it
+    hipEvent_t key_last_use = nullptr;  // recorded behind every launch that READS the scheduled round keys: the next aesw_schedule_key_device waits on it
+    bool key_used = false;
     bool xt = false;
     int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
@@ -234,6 +236,7 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
         if (rc == AESW_OK) T(hipMemcpy(ctx->d_ftab[l], ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(flush table)");
     }
     T(hipEventCreateWithFlags(&ctx->key_ready, hipEventDisableTiming), "hipEventCreate(key_ready)");
+    T(hipEventCreateWithFlags(&ctx->key_last_use, hipEventDisableTiming), "hipEventCreate(key_last_use)");
     if (rc == AESW_OK) T(warm_launch_attributes(), "hipFuncSetAttribute(max dynamic LDS)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_pidx, pidx.data(), pidx.size() * sizeof(int16_t), hipMemcpyHostToDevice), "hipMemcpy(pidx)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
@@ -264,6 +267,7 @@ void aesw_destroy(aesw_ctx *ctx) {
         for (uint32_t *t : ctx->d_ftab)
             if (t) (void)hipFree(t);
         if (ctx->key_ready) (void)hipEventDestroy(ctx->key_ready);
+        if (ctx->key_last_use) (void)hipEventDestroy(ctx->key_last_use);
     }
     delete ctx;
 }
@@ -499,6 +503,12 @@ int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, co
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     KeyParams kp{d_key, ctx->d_tables, ko, ctx->d_rk, 1, 0, 0};
+    {   // write-after-read: launches on OTHER streams may still be reading the previous key's round keys
+        hipStream_t ks_ = reinterpret_cast<hipStream_t>(stream);
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ks_, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (ctx->key_used && cs == hipStreamCaptureStatusNone) HIP_TRY(ctx, hipStreamWaitEvent(ks_, ctx->key_last_use, 0));
+    }
     HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, 0u, reinterpret_cast<hipStream_t>(stream)));
     // a later encrypt on ANOTHER stream (the host-pointer entry points use the context's own) waits for these round keys
     HIP_TRY(ctx, hipEventRecord(ctx->key_ready, reinterpret_cast<hipStream_t>(stream)));
@@ -559,6 +569,14 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
 #endif
     HIP_TRY(ctx, launch_encrypt(p, layout, ctx->xt, km, per_block_keys && kemit, auto_waves(ctx, layout, per_block_keys != 0),
                                 ctx->nt, (uint32_t)ctx->grid_cap, ctx->xcd_remap, (uint32_t)ctx->lds_pad, s));
+    if (km == 2) {  // this launch reads the scheduled round keys: the next aesw_schedule_key_device must not overwrite them under it
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            HIP_TRY(ctx, hipEventRecord(ctx->key_last_use, s));
+            ctx->key_used = true;
+        }
+    }
     return AESW_OK;
 }
 

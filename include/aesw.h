@@ -164,8 +164,9 @@ int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]);
  * reference's call shape: schedule_key once, encrypt many times
  * (benches/aes128.rs:50-53).  The round keys are written on `stream`: later
  * an encrypt call on another stream is ordered behind them with an event (no host wait).  The
- * context holds ONE scheduled key: scheduling another key while launches that use the previous one
- * are still running on a different stream races; synchronise first.  Inside a hipGraph capture the
+ * context holds ONE scheduled key: scheduling another key is ordered behind the launches that still read the
+ * previous one on other streams (an event recorded behind every scheduled-key launch; launches inside a
+ * hipGraph capture are not tracked: synchronise before re-scheduling under a captured graph).  Inside a hipGraph capture the
  * scheduled-key encrypt must be captured on the stream the key was scheduled on: on any other stream the
  * call returns AESW_ERR_INVALID_ARG (the dependency on the round keys could not be captured).
  * All launch attributes (dynamic LDS sizes) are set by aesw_create(): launches never change function

@@ -172,3 +172,36 @@ def test_assemble_oneshot_geometry_equals_the_striding_kernel_and_synthesize(ctx
     with oracle.circuit(k, n_sets, key, pts, record_copies=False) as c:
         for col in range(3 * n_sets + 1):
             assert np.array_equal(outs[1][col], lut[c.advice(col)]), col
+
+
+def test_rescheduling_a_key_waits_for_launches_still_reading_the_old_one(pkg, oracle):
+    """re-scheduling on stream A while stream B still reads the previous round keys was a write-after-read race.
+    The context now records an event behind every scheduled-key launch and aesw_schedule_key_device waits on it: a long
+    launch with key A on one stream, key B scheduled on another stream right behind it, and the long launch's output is
+    still key A's witness in every block; the next launch uses key B."""
+    import torch
+    c = pkg.Context(0)
+    rng = np.random.default_rng(123)
+    n = 1 << 18
+    pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    key_a, key_b = rng.integers(0, 256, 16, dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)
+    dpt, da, db = torch.from_numpy(pt).cuda(), torch.from_numpy(key_a).cuda(), torch.from_numpy(key_b).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    out_a = c.alloc_witness(n, pkg.LAYOUT_PACKED, want_ct=True)
+    out_b = c.alloc_witness(4096, pkg.LAYOUT_PACKED, want_ct=True)
+    torch.cuda.synchronize()
+    for _ in range(3):  # several rounds: the race, when present, does not show every time
+        with torch.cuda.stream(s1):
+            c.schedule_key(da, key_slab=False)
+        with torch.cuda.stream(s2):
+            c.encrypt_witness(dpt, None, out=out_a, want_ct=True)   # waits for key A, then runs ~0.1 ms
+        with torch.cuda.stream(s1):
+            c.schedule_key(db, key_slab=False)                        # must wait for the launch above
+            c.encrypt_witness(dpt[:4096], None, out=out_b, want_ct=True)
+        torch.cuda.synchronize()
+        ea = oracle.encrypt_witness(pt, key_a, layout=ol.PACKED)
+        eb = oracle.encrypt_witness(pt[:4096], key_b, layout=ol.PACKED)
+        assert np.array_equal(out_a.ct.cpu().numpy(), ea.ct)
+        assert np.array_equal(out_a.z.cpu().numpy(), ea.z)
+        assert np.array_equal(out_b.ct.cpu().numpy(), eb.ct)
+    c.close()
