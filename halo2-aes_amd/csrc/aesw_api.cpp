@@ -19,87 +19,13 @@
 
 using namespace aesw;
 
-struct aesw_ctx {
-    int device = -1;
-    uint8_t *d_tables = nullptr;  // 768 B
-    uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
-    uint8_t *d_rk = nullptr;      // 176 B: round keys of the key given to aesw_schedule_key*
-    int16_t *d_pidx = nullptr;    // dense row -> packed index tables: enc[3][1360], key[3][400]
-    uint32_t *d_ftab[3] = {nullptr, nullptr, nullptr};  // flush descriptors per layout (aesw_layout.h "scheduled flush")
-    bool have_key = false;
-    void *key_stream = nullptr;      // the stream the scheduled key's round keys were written on
-    hipEvent_t key_ready = nullptr;  // recorded behind the key launch of aesw_schedule_key_device: other streams wait on it
-    hipEvent_t key_last_use = nullptr;  // recorded behind every launch that READS the scheduled round keys: the next aesw_schedule_key_device waits on it
-    bool key_used = false;
-    bool xt = false;
-    int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
-    int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
-    int nt = 1;  // store flavour: 0 plain, 1 nontemporal (default since round 3), 2 write-through (sc1).  With all three flavours compiled to the
-                 // same code (round 3: they used to differ by 60 VGPRs, i.e. in residency) nontemporal stores are 1-3 % ahead at 2^20 blocks on
-                 // well-placed columns and within +-2 % of sc1 elsewhere (profiles/r03_study/README.md)
-    int key_nt = 1;  // store flavour of key_kernel (one contiguous flush per column at the end): nontemporal 4-9 % ahead of sc1 (tools/keysweep.py)
-    int fr_geo = 1;  // geometry of expand_fr: 1 = one-shot 4 KiB workgroups, LUT gathered from global memory: 7.3 TB/s with nontemporal stores
-                     // against 5.2 for 0 = striding workgroups + LDS LUT and 5.9 for 2 = one-shot 16 KiB + LDS LUT (tools/frsweep.py)
-    int asm_geo = 0;  // geometry of the Fr form of assemble: 0 = striding workgroups (default: 5.6 TB/s for K=20, N=5), 1 = division-free one-shot
-                      // workgroups on a (chunk, segment, column) grid (round 3: byte-exact, 5.2 TB/s -- a piece is a chain of three dependent loads
-                      // (index table, slab byte, LUT) and a one-shot workgroup has nothing else in flight: latency x residency bounds it, not divisions)
-    int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)
-    int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
-    uint32_t xcd_remap = 1;  // xcd_group() mode: 0 dispatch order, 1 one contiguous eighth of the groups per XCD (+3-4 % at 2^20 blocks over 0, tools/sweep.py xcd), C >= 2 turns of C groups
-    int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
-    int arena_align_log2 = 0;  // aesw_columns_alloc: column alignment (0 = auto: 2 MiB)
-    int arena_probe = -1;      // candidate backings aesw_columns_alloc measures per unit (-1 = auto, 0 = none: one hipMalloc)
-    double best_fill_us_per_gb = 0;  // fastest linear fill any arena search of this context has seen (us per 10^9 bytes): the probe's yardstick
-    int arena_unit = 2;        // what a candidate is: 0 = the whole set of columns in one range, 1 = one column (greedy, largest first),
-                               // 2 = whole sets first, columns if no set candidate runs the pattern as fast as its fill (default)
-    struct ArenaRange { void *p; size_t bytes; bool vmm; };  // vmm: built with the virtual-memory API (freed by unmap), else hipMalloc
-    struct ArenaRec { void *key; std::vector<ArenaRange> ranges; };
-    std::vector<ArenaRec> vmm_arenas;  // arenas built with the virtual-memory API (one range per column; freed by unmap, not hipFree)
-#ifdef AESW_TRACE
-    uint64_t *trace = nullptr;
-#endif
-    int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
-    std::string last_error;
-    hipStream_t s_compute = nullptr, s_copy = nullptr;
-    uint8_t *bounce[2] = {nullptr, nullptr};  // page-locked staging for pageable destinations
-    size_t bounce_bytes = 0;
-    uint8_t *scratch = nullptr;  // device buffers of the host-pointer path (grow-only)
-    size_t scratch_bytes = 0;
-    aesw_stream_stats stats = {};  // of the last streaming call
-};
+#include "aesw_ctx.h"
 
 namespace {
 
-int fail_hip(aesw_ctx *ctx, hipError_t e, const char *what) {
-    if (ctx) {
-        char buf[256];
-        std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-        ctx->last_error = buf;
-    }
-    return e == hipErrorOutOfMemory ? AESW_ERR_NOMEM : AESW_ERR_HIP;
-}
-
-#define HIP_TRY(ctx, expr)                                  \
-    do {                                                    \
-        hipError_t e_ = (expr);                             \
-        if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr); \
-    } while (0)
-
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = false;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = hipSetDevice(dev) == hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
-bool valid_layout(int l) { return l == AESW_LAYOUT_DENSE || l == AESW_LAYOUT_PACKED || l == AESW_LAYOUT_VALUES; }
+bool valid_layout(int l) { return aesw_valid_layout(l); }
 
 uint8_t xtime(uint8_t a) { return (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0)); }
 
@@ -655,269 +581,6 @@ int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cell
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     HIP_TRY(ctx, launch_expand_fr(d_cells, n_cells, ctx->d_fr_lut, d_fr, ctx->fr_nt, ctx->fr_geo, reinterpret_cast<hipStream_t>(stream)));
-    return AESW_OK;
-}
-
-// ---- one arena for every output column of a batch, chosen by measurement -----------------
-// (include/aesw.h "Placement probing"; the study behind it: profiles/r03_study/README.md, tools/allocbench.hip)
-
-namespace {
-
-// A virtual range of `total` bytes backed by physical chunks of `chunk` bytes each (the last one shorter).
-int vmm_build(aesw_ctx *ctx, size_t total, size_t chunk, void **out) {
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = ctx->device;
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
-    void *va = nullptr;
-    HIP_TRY(ctx, hipMemAddressReserve(&va, total, 0, nullptr, 0));
-    size_t mapped = 0;
-    hipError_t e = hipSuccess;
-    while (mapped < total && e == hipSuccess) {
-        const size_t sz = total - mapped < chunk ? total - mapped : chunk;
-        hipMemGenericAllocationHandle_t h;
-        e = hipMemCreate(&h, sz, &prop, 0);
-        if (e != hipSuccess) break;
-        e = hipMemMap(reinterpret_cast<uint8_t *>(va) + mapped, sz, 0, h, 0);
-        (void)hipMemRelease(h);  // the mapping keeps the chunk alive; an unmapped chunk is gone with this
-        if (e == hipSuccess) mapped += sz;
-    }
-    if (e == hipSuccess) e = hipMemSetAccess(va, total, &acc, 1);
-    if (e != hipSuccess) {
-        if (mapped) (void)hipMemUnmap(va, mapped);
-        (void)hipMemAddressFree(va, total);
-        return fail_hip(ctx, e, "virtual-memory arena (hipMemCreate / hipMemMap / hipMemSetAccess)");
-    }
-    *out = va;
-    return AESW_OK;
-}
-
-void vmm_release(void *va, size_t total) {
-    (void)hipMemUnmap(va, total);
-    (void)hipMemAddressFree(va, total);
-}
-
-}  // namespace
-
-int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab, int with_ct, aesw_columns *out) {
-    if (!ctx || !out || !valid_layout(layout) || n == 0 || n > ((uint64_t)1 << 40)) return AESW_ERR_INVALID_ARG;
-    std::memset(out, 0, sizeof *out);
-    const uint64_t sx = aesw_column_stride(layout, 0), sy = aesw_column_stride(layout, 1), sz = aesw_column_stride(layout, 2);
-    const uint64_t align = ctx->arena_align_log2 ? (uint64_t)1 << ctx->arena_align_log2 : (uint64_t)2 << 20;
-    // sizes in the order the columns are laid out; a column of size 0 takes no room
-    const uint64_t size[8] = {n * sx, n * sy, n * sz, with_ct ? n * 16 : 0,
-                              with_key_slab ? n * WORDS_ROWS : 0, with_key_slab ? n * aesw_key_column_stride(layout, 0) : 0,
-                              with_key_slab ? n * aesw_key_column_stride(layout, 1) : 0, with_key_slab ? n * aesw_key_column_stride(layout, 2) : 0};
-    uint64_t off[8], end = 0;
-    for (int i = 0; i < 8; ++i) {
-        end = (end + align - 1) / align * align;
-        off[i] = end;
-        end += size[i];
-    }
-    DeviceGuard g(ctx->device);
-    if (!g.ok) return AESW_ERR_NO_DEVICE;
-    auto fill_out = [&](uint8_t *b) {
-        auto at = [&](int i) -> uint8_t * { return size[i] ? b + off[i] : nullptr; };
-        out->x = at(0); out->y = at(1); out->z = at(2); out->ct = at(3);
-        out->key.w = at(4); out->key.kx = at(5); out->key.ky = at(6); out->key.kz = at(7);
-    };
-    int probe = ctx->arena_probe < 0 ? (n >= ((uint64_t)1 << 16) ? 8 : 0) : ctx->arena_probe;
-    if (probe == 0) {
-        // hipMalloc returns memory aligned to the allocation granule only: over-allocate by one alignment unit
-        uint8_t *raw = nullptr;
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&raw), end + align));
-        out->base = raw;
-        out->bytes = end + align;
-        fill_out(raw + (align - reinterpret_cast<uintptr_t>(raw) % align) % align);
-        return AESW_OK;
-    }
-    // Search by measurement.  A UNIT is what one candidate backs: the whole set of columns in one range ("arena_unit" 0), or
-    // one column ("arena_unit" 1: greedy, largest column first).  For every unit up to `probe` candidates are built -- a plain
-    // hipMalloc, then virtual ranges over physical chunks of 8 / 2 / 32 / 4 MiB, and round again --, the store-pattern
-    // emulation and a linear fill are timed over the units chosen so far PLUS the candidate, the candidate with the best
-    // ratio is kept (the search of a unit stops at the first candidate whose pattern runs as fast as its fill).  Candidates
-    // that lose are HELD until the whole search is over (otherwise the driver hands the same memory out again), then released.
-    using Range = aesw_ctx::ArenaRange;
-    const uint32_t strides7[7] = {(uint32_t)sx, (uint32_t)sy, (uint32_t)sz, WORDS_ROWS, aesw_key_column_stride(layout, 0),
-                                  aesw_key_column_stride(layout, 1), aesw_key_column_stride(layout, 2)};
-    const int size_of7[7] = {0, 1, 2, 4, 5, 6, 7};  // probe column c (x y z w kx ky kz) -> index into size[] / off[]
-    const size_t MiB2 = (size_t)2 << 20;
-    auto round2m = [&](uint64_t v) { return (size_t)((v + MiB2 - 1) / MiB2 * MiB2); };
-    auto release = [](const Range &r) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); };
-    auto build = [&](int kind, size_t bytes, Range *r) -> int {
-        static const size_t chunk_of[4] = {(size_t)8 << 20, (size_t)2 << 20, (size_t)32 << 20, (size_t)4 << 20};
-        if (kind % 5 == 0) {
-            void *q = nullptr;
-            HIP_TRY(ctx, hipMalloc(&q, bytes));  // 2 MiB aligned for allocations of this size
-            *r = Range{q, bytes, false};
-            return AESW_OK;
-        }
-        void *va = nullptr;
-        const int rc = vmm_build(ctx, bytes, chunk_of[(kind % 5) - 1], &va);
-        if (rc == AESW_OK) *r = Range{va, bytes, true};
-        return rc;
-    };
-    aesw_ctx::ArenaRec rec{nullptr, {}};
-    std::vector<Range> losers;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    bool done = false;
-    struct Cleanup {
-        aesw_ctx::ArenaRec &rec; std::vector<Range> &losers; bool &done; hipEvent_t &a, &b, &d, &e;
-        ~Cleanup() {
-            for (auto &r : losers) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); }
-            if (!done)
-                for (auto &r : rec.ranges) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); }
-            if (a) (void)hipEventDestroy(a);
-            if (b) (void)hipEventDestroy(b);
-            if (d) (void)hipEventDestroy(d);
-            if (e) (void)hipEventDestroy(e);
-        }
-    } cleanup{rec, losers, done, e0, e1, e2, e3};
-    HIP_TRY(ctx, hipEventCreate(&e3));
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
-    HIP_TRY(ctx, hipEventCreate(&e2));
-    ProbeParams pp = {};
-    for (int c = 0; c < 7; ++c) pp.stride[c] = strides7[c];
-    pp.n = n;
-    pp.xcd_mode = ctx->xcd_remap;
-    // two timed passes of a 2^20-block set; proportionally more for smaller batches (short launches time noisily)
-    const int passes = n >= ((uint64_t)1 << 20) ? 2 : (int)std::min<uint64_t>(32, (((uint64_t)1 << 21) + n - 1) / n);
-    uint32_t total_cands = 0;
-    struct Placement {
-        std::vector<Range> ranges;
-        uint8_t *col[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        uint8_t *ct = nullptr;
-        float probe_us = 0.f, fill_us = 1.f;
-        int rc = AESW_OK;
-    };
-    // one search: unit_mode 0 = whole-set candidates, 1 = one column at a time (greedy, largest first)
-    auto search = [&](int unit_mode) -> Placement {
-        Placement pl;
-        ProbeParams q = pp;
-        for (int c = 0; c < 7; ++c) q.col[c] = nullptr;
-        std::vector<std::vector<int>> units;
-        if (unit_mode == 0) {
-            units.push_back({0, 1, 2, 3, 4, 5, 6});
-        } else {
-            int order[7] = {0, 1, 2, 3, 4, 5, 6};
-            std::sort(order, order + 7, [&](int a, int b) { return size[size_of7[a]] > size[size_of7[b]]; });
-            for (int c : order)
-                if (size[size_of7[c]]) units.push_back({c});
-        }
-        auto fail = [&](int rc) { for (auto &r : pl.ranges) losers.push_back(r); pl.ranges.clear(); pl.rc = rc; return pl; };
-        auto hip = [&](hipError_t e, const char *what) { return e == hipSuccess ? AESW_OK : fail_hip(ctx, e, what); };
-        for (size_t ui = 0; ui < units.size(); ++ui) {
-            const std::vector<int> &cols = units[ui];
-            // layout of the unit: its columns one after the other on 2 MiB boundaries (the ciphertext rides with a whole-set unit)
-            size_t uoff[8], ubytes = 0;
-            for (int c : cols) { uoff[c] = ubytes; ubytes += round2m(size[size_of7[c]]); }
-            const bool with_ct_here = unit_mode == 0 && size[3];
-            if (with_ct_here) { uoff[7] = ubytes; ubytes += round2m(size[3]); }
-            if (!ubytes) continue;
-            Range best{nullptr, 0, false};
-            float best_probe = 0.f, best_fill = 1.f;
-            float ref_fill = 0.f;  // the fastest linear fill seen for this unit: one slow fill sample must not make a candidate look good
-            for (int k = 0; k < probe; ++k) {
-                Range r{nullptr, 0, false};
-                int rc = build(k + (int)ui, ubytes, &r);
-                if (rc != AESW_OK) {
-                    if (!best.p) return fail(rc);  // not even one candidate for this unit fits
-                    break;                         // memory is getting short: choose among what we have
-                }
-                losers.push_back(r);  // owned by ~Cleanup unless chosen below
-                ++total_cands;
-                for (int c : cols) q.col[c] = size[size_of7[c]] ? reinterpret_cast<uint8_t *>(r.p) + uoff[c] : nullptr;
-                rc = hip(launch_probe(q, false, nullptr), "probe launch");  // first touch + warm-up, untimed
-                if (rc == AESW_OK) rc = hip(hipEventRecord(e0, nullptr), "hipEventRecord");
-                for (int i = 0; i < passes && rc == AESW_OK; ++i) rc = hip(launch_probe(q, false, nullptr), "probe launch");
-                if (rc == AESW_OK) rc = hip(hipEventRecord(e1, nullptr), "hipEventRecord");
-                if (rc == AESW_OK) rc = hip(launch_probe(q, true, nullptr), "probe launch");  // one untimed fill: the first one after a search's releases runs slow
-                if (rc == AESW_OK) rc = hip(hipEventRecord(e3, nullptr), "hipEventRecord");
-                for (int i = 0; i < passes && rc == AESW_OK; ++i) rc = hip(launch_probe(q, true, nullptr), "probe launch");
-                if (rc == AESW_OK) rc = hip(hipEventRecord(e2, nullptr), "hipEventRecord");
-                if (rc == AESW_OK) rc = hip(hipEventSynchronize(e2), "hipEventSynchronize");
-                float f = 0, l = 0;
-                if (rc == AESW_OK) rc = hip(hipEventElapsedTime(&f, e0, e1), "hipEventElapsedTime");
-                if (rc == AESW_OK) rc = hip(hipEventElapsedTime(&l, e3, e2), "hipEventElapsedTime");
-                if (rc != AESW_OK) return fail(rc);
-                {   // the yardstick: the fastest fill seen for this unit, and no slower than the fastest fill per byte this context ever saw
-                    double probed_bytes = 0;
-                    for (int c = 0; c < 7; ++c) if (q.col[c]) probed_bytes += (double)n * q.stride[c];
-                    if (probed_bytes >= 1e9) {  // launches long enough that time per byte is a rate, not ramp and tail
-                        const double per_gb = (double)l * 1e3 / passes / (probed_bytes * 1e-9);
-                        if (ctx->best_fill_us_per_gb == 0 || per_gb < ctx->best_fill_us_per_gb) ctx->best_fill_us_per_gb = per_gb;
-                        const float floor_ms = (float)(ctx->best_fill_us_per_gb * probed_bytes * 1e-9 * passes * 1e-3);
-                        if (l > 1.03f * floor_ms) l = 1.03f * floor_ms;
-                    }
-                }
-                if (ref_fill == 0.f || l < ref_fill) ref_fill = l;
-                const float ratio = f / ref_fill;
-                if (!best.p || f < best_probe * passes * 1e-3f) { best = r; best_probe = f * 1e3f / passes; }
-                best_fill = ref_fill * 1e3f / passes;
-                if (ratio <= 1.025f) break;  // the many-front pattern as fast as a linear fill (the two levels are 0.98 - 1.02 and >= 1.05): as good as it gets
-            }
-            for (size_t i = 0; i < losers.size(); ++i)
-                if (losers[i].p == best.p) { losers.erase(losers.begin() + (long)i); break; }
-            pl.ranges.push_back(best);
-            for (int c : cols) q.col[c] = size[size_of7[c]] ? reinterpret_cast<uint8_t *>(best.p) + uoff[c] : nullptr;
-            if (with_ct_here) pl.ct = reinterpret_cast<uint8_t *>(best.p) + uoff[7];
-            pl.probe_us = best_probe;  // after the last unit: the whole set as finally placed
-            pl.fill_us = best_fill;
-        }
-        if (size[3] && !pl.ct) {  // column units: the ciphertext is one small linear stream outside the pattern: any backing
-            Range r{nullptr, 0, false};
-            const int rc = build(1, round2m(size[3]), &r);
-            if (rc != AESW_OK) return fail(rc);
-            pl.ranges.push_back(r);
-            pl.ct = reinterpret_cast<uint8_t *>(r.p);
-        }
-        for (int c = 0; c < 7; ++c) pl.col[c] = q.col[c];
-        return pl;
-    };
-    // "arena_unit" 2 (default): whole-set candidates first; when none of them runs the pattern as fast as its fill, a second
-    // search places the columns one at a time (the whole-set losers stay held meanwhile) and the better of the two is kept
-    Placement pl = search(ctx->arena_unit == 1 ? 1 : 0);
-    if (pl.rc != AESW_OK) return pl.rc;
-    if (ctx->arena_unit == 2 && pl.probe_us > 1.025f * pl.fill_us) {
-        Placement alt = search(1);
-        if (alt.rc == AESW_OK && alt.probe_us / alt.fill_us < pl.probe_us / pl.fill_us) std::swap(pl, alt);
-        for (auto &r : alt.ranges) losers.push_back(r);  // the search that lost (or failed half-way: already handed over)
-    }
-    rec.ranges = pl.ranges;
-    out->x = pl.col[0]; out->y = pl.col[1]; out->z = pl.col[2]; out->ct = pl.ct;
-    out->key.w = pl.col[3]; out->key.kx = pl.col[4]; out->key.ky = pl.col[5]; out->key.kz = pl.col[6];
-    out->base = out->y;  // the handle aesw_columns_free looks the arena up by (every layout has a y column)
-    for (auto &r : rec.ranges) out->bytes += r.bytes;
-    out->candidates = total_cands;
-    out->chosen = 0;
-    out->probe_us = pl.probe_us;
-    out->fill_us = pl.fill_us;
-    rec.key = out->base;
-    ctx->vmm_arenas.push_back(rec);
-    done = true;
-    return AESW_OK;  // ~Cleanup releases the candidates that were not chosen
-}
-
-int aesw_columns_free(aesw_ctx *ctx, aesw_columns *cols) {
-    if (!ctx || !cols) return AESW_ERR_INVALID_ARG;
-    if (cols->base) {
-        DeviceGuard g(ctx->device);
-        if (!g.ok) return AESW_ERR_NO_DEVICE;
-        bool vmm = false;
-        for (size_t i = 0; i < ctx->vmm_arenas.size(); ++i)
-            if (ctx->vmm_arenas[i].key == cols->base) {
-                for (auto &r : ctx->vmm_arenas[i].ranges) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); }
-                ctx->vmm_arenas.erase(ctx->vmm_arenas.begin() + (long)i);
-                vmm = true;
-                break;
-            }
-        if (!vmm) HIP_TRY(ctx, hipFree(cols->base));
-    }
-    std::memset(cols, 0, sizeof *cols);
     return AESW_OK;
 }
 

@@ -1,0 +1,88 @@
+// aesw_ctx.h -- the opaque context of include/aesw.h and the small helpers every translation unit of the C ABI uses
+// (aesw_api.cpp: entry points; aesw_arena.cpp: the probed column arena).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/aesw.h"
+
+struct aesw_ctx {
+    int device = -1;
+    uint8_t *d_tables = nullptr;  // 768 B
+    uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
+    uint8_t *d_rk = nullptr;      // 176 B: round keys of the key given to aesw_schedule_key*
+    int16_t *d_pidx = nullptr;    // dense row -> packed index tables: enc[3][1360], key[3][400]
+    uint32_t *d_ftab[3] = {nullptr, nullptr, nullptr};  // flush descriptors per layout (aesw_layout.h "scheduled flush")
+    bool have_key = false;
+    void *key_stream = nullptr;      // the stream the scheduled key's round keys were written on
+    hipEvent_t key_ready = nullptr;  // recorded behind the key launch of aesw_schedule_key_device: other streams wait on it
+    hipEvent_t key_last_use = nullptr;  // recorded behind every launch that READS the scheduled round keys: the next aesw_schedule_key_device waits on it
+    bool key_used = false;
+    bool xt = false;
+    int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
+    int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)
+    int nt = 1;  // store flavour: 0 plain, 1 nontemporal (default since round 3), 2 write-through (sc1).  With all three flavours compiled to the
+                 // same code (round 3: they used to differ by 60 VGPRs, i.e. in residency) nontemporal stores are 1-3 % ahead at 2^20 blocks on
+                 // well-placed columns and within +-2 % of sc1 elsewhere (profiles/r03_study/README.md)
+    int key_nt = 1;  // store flavour of key_kernel (one contiguous flush per column at the end): nontemporal 4-9 % ahead of sc1 (tools/keysweep.py)
+    int fr_geo = 1;  // geometry of expand_fr: 1 = one-shot 4 KiB workgroups, LUT gathered from global memory: 7.3 TB/s with nontemporal stores
+                     // against 5.2 for 0 = striding workgroups + LDS LUT and 5.9 for 2 = one-shot 16 KiB + LDS LUT (tools/frsweep.py)
+    int asm_geo = 0;  // geometry of the Fr form of assemble: 0 = striding workgroups (default: 5.6 TB/s for K=20, N=5), 1 = division-free one-shot
+                      // workgroups on a (chunk, segment, column) grid (round 3: byte-exact, 5.2 TB/s -- a piece is a chain of three dependent loads
+                      // (index table, slab byte, LUT) and a one-shot workgroup has nothing else in flight: latency x residency bounds it, not divisions)
+    int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)
+    int64_t grid_cap = 0;  // max workgroups per launch (0 = one per block group)
+    uint32_t xcd_remap = 1;  // xcd_group() mode: 0 dispatch order, 1 one contiguous eighth of the groups per XCD (+3-4 % at 2^20 blocks over 0, tools/sweep.py xcd), C >= 2 turns of C groups
+    int64_t lds_pad = 0;  // diagnostic (tools/occ.py): extra dynamic LDS per workgroup, lowers residency
+    int arena_align_log2 = 0;  // aesw_columns_alloc: column alignment (0 = auto: 2 MiB)
+    int arena_probe = -1;      // candidate backings aesw_columns_alloc measures per unit (-1 = auto, 0 = none: one hipMalloc)
+    double best_fill_us_per_gb = 0;  // fastest linear fill any arena search of this context has seen (us per 10^9 bytes): the probe's yardstick
+    int arena_unit = 2;        // what a candidate is: 0 = the whole set of columns in one range, 1 = one column (greedy, largest first),
+                               // 2 = whole sets first, columns if no set candidate runs the pattern as fast as its fill (default)
+    struct ArenaRange { void *p; size_t bytes; bool vmm; };  // vmm: built with the virtual-memory API (freed by unmap), else hipMalloc
+    struct ArenaRec { void *key; std::vector<ArenaRange> ranges; };
+    std::vector<ArenaRec> vmm_arenas;  // arenas built with the virtual-memory API (one range per column; freed by unmap, not hipFree)
+#ifdef AESW_TRACE
+    uint64_t *trace = nullptr;
+#endif
+    int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
+    std::string last_error;
+    hipStream_t s_compute = nullptr, s_copy = nullptr;
+    uint8_t *bounce[2] = {nullptr, nullptr};  // page-locked staging for pageable destinations
+    size_t bounce_bytes = 0;
+    uint8_t *scratch = nullptr;  // device buffers of the host-pointer path (grow-only)
+    size_t scratch_bytes = 0;
+    aesw_stream_stats stats = {};  // of the last streaming call
+};
+
+inline int fail_hip(aesw_ctx *ctx, hipError_t e, const char *what) {
+    if (ctx) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        ctx->last_error = buf;
+    }
+    return e == hipErrorOutOfMemory ? AESW_ERR_NOMEM : AESW_ERR_HIP;
+}
+
+#define HIP_TRY(ctx, expr)                                  \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline bool aesw_valid_layout(int l) { return l == AESW_LAYOUT_DENSE || l == AESW_LAYOUT_PACKED || l == AESW_LAYOUT_VALUES; }

@@ -13,7 +13,7 @@ DIAG = ROOT / "tools" / "libaesw_diag.so"
 if not DIAG.exists():
     csrc = ROOT / "halo2-aes_amd" / "csrc"
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DAESW_DIAGNOSTIC", "-o", str(DIAG),
-                           str(csrc / "aesw_kernels.hip"), str(csrc / "aesw_api.cpp"), str(csrc / "aesw_comm.cpp")])
+                           str(csrc / "aesw_kernels.hip"), str(csrc / "aesw_api.cpp"), str(csrc / "aesw_arena.cpp"), str(csrc / "aesw_comm.cpp")])
 if "--build-only" in sys.argv:
     sys.exit(0)
 import torch  # noqa: E402

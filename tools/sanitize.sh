@@ -6,7 +6,7 @@
 set -eu
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
-SRC="halo2-aes_amd/csrc/aesw_kernels.hip halo2-aes_amd/csrc/aesw_api.cpp halo2-aes_amd/csrc/aesw_comm.cpp halo2-aes_amd/host/host_capi.cpp"
+SRC="halo2-aes_amd/csrc/aesw_kernels.hip halo2-aes_amd/csrc/aesw_api.cpp halo2-aes_amd/csrc/aesw_arena.cpp halo2-aes_amd/csrc/aesw_comm.cpp halo2-aes_amd/host/host_capi.cpp"
 if [ ! -f tools/libaesw_asan.so ] || [ -n "$(find $SRC halo2-aes_amd/csrc/*.h halo2-aes_amd/host/*.hpp -newer tools/libaesw_asan.so)" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined \
         -Xarch_host -fno-omit-frame-pointer -Xarch_host -g -o tools/libaesw_asan.so $SRC

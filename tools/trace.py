@@ -18,7 +18,7 @@ pkg = ge.load_package()
 b = ge._load_build()
 lib_path = ROOT / "tools" / "libaesw_trace.so"
 csrc, host = ROOT / "halo2-aes_amd" / "csrc", ROOT / "halo2-aes_amd" / "host"
-srcs = [csrc / "aesw_kernels.hip", csrc / "aesw_api.cpp", host / "host_capi.cpp"]
+srcs = [csrc / "aesw_kernels.hip", csrc / "aesw_api.cpp", csrc / "aesw_arena.cpp", host / "host_capi.cpp"]
 if not b._newer(lib_path, srcs + [csrc / "aesw_lane.h", csrc / "aesw_layout.h", csrc / "aesw_internal.h"]):
     b._run([b.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DAESW_TRACE",
             "-o", str(lib_path)] + [str(s) for s in srcs])
