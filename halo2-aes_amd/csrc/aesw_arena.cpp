@@ -184,9 +184,15 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
             float best_probe = 0.f, best_fill = 1.f;
             float ref_fill = 0.f;  // the fastest linear fill seen for this unit: one slow fill sample must not make a candidate look good
             for (int k = 0; k < probe; ++k) {
+                if (best.p) {  // the losers are held until the search ends: never let them take the device's last memory
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+                    if (free_b < ubytes + ((size_t)16 << 30)) break;
+                }
                 Range r{nullptr, 0, false};
                 int rc = build(k + (int)ui, ubytes, &r);
                 if (rc != AESW_OK) {
+                    (void)hipGetLastError();       // an out-of-memory here must not surface from the next launch's error check
                     if (!best.p) return fail(rc);  // not even one candidate for this unit fits
                     break;                         // memory is getting short: choose among what we have
                 }

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -35,7 +36,66 @@ __global__ void __launch_bounds__(256) k_fill(uint8_t *out, size_t total) {
     if (p < total) st(out + p, v);
 }
 
+// "spacing" mode: is it the PHYSICAL DISTANCE between the regions written at once?  One column (2^20 blocks x stride) whose
+// eight XCD windows (an eighth of the column each, what xcd_remap 1 makes every XCD write) are eight separate physical
+// chunks with filler allocations of S bytes created between them (held while measuring), so that consecutive windows lie
+// about S apart in whatever order the driver hands physical memory out.
+static int spacing_mode(int stride) {
+    const uint32_t nblk = 1u << 20;
+    const size_t bytes = (size_t)nblk * stride, win = bytes / 8;  // 2^17 blocks x stride: a multiple of 2 MiB for every stride used
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto timeit = [&](auto launch) {
+        launch();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 4; ++i) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        return ms * 1e3 / 4;
+    };
+    printf("one column of %zu bytes as 8 chunks (one per XCD window), filler of S bytes between consecutive chunks\n", bytes);
+    for (int rep = 0; rep < 3; ++rep)
+        for (size_t S : {(size_t)0, (size_t)256 << 20, (size_t)1 << 30, (size_t)4 << 30, (size_t)0}) {
+            void *va = nullptr;
+            CK(hipMemAddressReserve(&va, bytes, 0, nullptr, 0));
+            std::vector<hipMemGenericAllocationHandle_t> fillers;
+            for (int w = 0; w < 8; ++w) {
+                hipMemGenericAllocationHandle_t h;
+                CK(hipMemCreate(&h, win, &prop, 0));
+                CK(hipMemMap((uint8_t *)va + (size_t)w * win, win, 0, h, 0));
+                CK(hipMemRelease(h));
+                if (S && w < 7) {
+                    hipMemGenericAllocationHandle_t f;
+                    CK(hipMemCreate(&f, S, &prop, 0));
+                    fillers.push_back(f);
+                }
+            }
+            CK(hipMemSetAccess(va, bytes, &acc, 1));
+            uint8_t *b = (uint8_t *)va;
+            const double f = timeit([&] { hipLaunchKernelGGL(k_fronts, dim3(nblk / 16), dim3(64), 0, 0, b, nblk, stride); });
+            const double l = timeit([&] { hipLaunchKernelGGL(k_fill, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, 0, b, bytes); });
+            printf("rep %d  filler %5zu MiB   fronts %7.1f us  fill %7.1f us  ratio %.3f\n", rep, S >> 20, f, l, f / l);
+            fflush(stdout);
+            for (auto h : fillers) CK(hipMemRelease(h));
+            CK(hipMemUnmap(va, bytes));
+            CK(hipMemAddressFree(va, bytes));
+        }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "spacing")) return spacing_mode(argc > 2 ? atoi(argv[2]) : 1360);
     const int N = argc > 1 ? atoi(argv[1]) : 16;
     const int stride = argc > 2 ? atoi(argv[2]) : 1360;
     const uint32_t nblk = 1u << 20;
