@@ -422,13 +422,15 @@ class Context:
                                for c in range(3)], None)
         return Witness(cols[0], cols[1], cols[2], ct, key)
 
-    def alloc_columns(self, n: int, layout: int = K.LAYOUT_PACKED, want_ct: bool = False, key_slab: bool = False):
+    def alloc_columns(self, n: int, layout: int = K.LAYOUT_PACKED, want_ct: bool = False, key_slab: bool = False, key_only: bool = False):
         """alloc_witness through the C ABI's arena (aesw_columns_alloc): ONE device allocation, every column on an
         aligned boundary (option "arena_align_log2"; auto = 1 GiB for large batches).  The returned Witness's tensors
         are views of that allocation, which lives until free_columns(witness) or the Context is closed."""
         torch = self._torch()
         cols = Columns()
-        self._check(self._lib.aesw_columns_alloc(self._h, n, layout, 1 if key_slab else 0, 1 if want_ct else 0, C.byref(cols)),
+        if key_only:
+            key_slab = True
+        self._check(self._lib.aesw_columns_alloc(self._h, n, layout, 2 if key_only else (1 if key_slab else 0), 1 if want_ct else 0, C.byref(cols)),
                     "aesw_columns_alloc")
         dev = self._dev()
 
@@ -437,21 +439,21 @@ class Context:
                 return torch.empty(0, dtype=torch.uint8, device=dev)
             return torch.as_tensor(_DevView(ptr, nbytes), device=dev)
 
-        x, y, z = (view(getattr(cols, c), n * column_stride(layout, i)) for i, c in enumerate("xyz"))
+        x, y, z = (view(getattr(cols, c), n * column_stride(layout, i) if not key_only else 0) for i, c in enumerate("xyz"))
         ct = view(cols.ct, n * 16).view(n, 16) if want_ct else None
         key = None
         if key_slab:
             key = KeyWitness(view(cols.key.w, n * K.WORDS_ROWS), *[view(getattr(cols.key, c), n * key_column_stride(layout, i))
                                                                    for i, c in enumerate(("kx", "ky", "kz"))], None)
         wit = Witness(x, y, z, ct, key)
-        self._arenas[y.data_ptr()] = cols  # every layout has a y column
+        self._arenas[(key.w if key_only else y).data_ptr()] = cols
         self.last_arena = {"candidates": int(cols.candidates), "chosen": int(cols.chosen), "probe_us": float(cols.probe_us),
                            "fill_us": float(cols.fill_us), "bytes": int(cols.bytes)}
         return wit
 
     def free_columns(self, wit) -> None:
         """Release the arena behind a Witness from alloc_columns (its tensors must not be used afterwards)."""
-        cols = self._arenas.pop(wit.y.data_ptr(), None)
+        cols = self._arenas.pop((wit.y if wit.y.numel() else wit.key.w).data_ptr(), None)
         if cols is None:
             raise ValueError("not a witness of alloc_columns (or already freed)")
         self._check(self._lib.aesw_columns_free(self._h, C.byref(cols)), "aesw_columns_free")
@@ -521,8 +523,9 @@ class Context:
         self._check(rc, "aesw_encrypt_witness_device")
         return out
 
-    def key_schedule_witness(self, keys, layout: int = K.LAYOUT_PACKED, want_rk: bool = True) -> KeyWitness:
-        """Aes128KeyScheduleConfig::schedule_keys witness for n keys (src/key_schedule.rs:80-224)."""
+    def key_schedule_witness(self, keys, layout: int = K.LAYOUT_PACKED, want_rk: bool = True, out: KeyWitness | None = None) -> KeyWitness:
+        """Aes128KeyScheduleConfig::schedule_keys witness for n keys (src/key_schedule.rs:80-224); into `out`
+        (e.g. alloc_columns(n, layout, key_only=True).key) when given."""
         torch = self._torch()
         keys = self._u8(keys, "keys")
         if keys.dim() == 1:
@@ -531,8 +534,15 @@ class Context:
             raise ValueError("keys must be [n,16]")
         n = keys.shape[0]
         dev = self._dev()
-        w = torch.empty(n * K.WORDS_ROWS, dtype=torch.uint8, device=dev)
-        kx, ky, kz = [torch.empty(n * key_column_stride(layout, c), dtype=torch.uint8, device=dev) for c in range(3)]
+        if out is not None:
+            w, kx, ky, kz = out[:4]
+            for t, need in ((w, n * K.WORDS_ROWS), (kx, n * key_column_stride(layout, 0)), (ky, n * key_column_stride(layout, 1)),
+                            (kz, n * key_column_stride(layout, 2))):
+                if self._u8(t, "out").numel() < need:
+                    raise ValueError("out column too small")
+        else:
+            w = torch.empty(n * K.WORDS_ROWS, dtype=torch.uint8, device=dev)
+            kx, ky, kz = [torch.empty(n * key_column_stride(layout, c), dtype=torch.uint8, device=dev) for c in range(3)]
         rk = torch.empty((n, 176), dtype=torch.uint8, device=dev) if want_rk else None
         rc = self._lib.aesw_key_schedule_witness_device(
             self._h, keys.data_ptr(), n, layout, w.data_ptr(), kx.data_ptr(), ky.data_ptr(), kz.data_ptr(),

@@ -67,7 +67,10 @@ void vmm_release(void *va, size_t total) {
 int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab, int with_ct, aesw_columns *out) {
     if (!ctx || !out || !valid_layout(layout) || n == 0 || n > ((uint64_t)1 << 40)) return AESW_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
-    const uint64_t sx = aesw_column_stride(layout, 0), sy = aesw_column_stride(layout, 1), sz = aesw_column_stride(layout, 2);
+    // with_key_slab 2: the key-schedule witness alone (aesw_key_schedule_witness_device): no encrypt columns
+    const bool key_only = with_key_slab == 2;
+    const uint64_t sx = key_only ? 0 : aesw_column_stride(layout, 0), sy = key_only ? 0 : aesw_column_stride(layout, 1),
+                   sz = key_only ? 0 : aesw_column_stride(layout, 2);
     const uint64_t align = ctx->arena_align_log2 ? (uint64_t)1 << ctx->arena_align_log2 : (uint64_t)2 << 20;
     // sizes in the order the columns are laid out; a column of size 0 takes no room
     const uint64_t size[8] = {n * sx, n * sy, n * sz, with_ct ? n * 16 : 0,
@@ -258,7 +261,7 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     rec.ranges = pl.ranges;
     out->x = pl.col[0]; out->y = pl.col[1]; out->z = pl.col[2]; out->ct = pl.ct;
     out->key.w = pl.col[3]; out->key.kx = pl.col[4]; out->key.ky = pl.col[5]; out->key.kz = pl.col[6];
-    out->base = out->y;  // the handle aesw_columns_free looks the arena up by (every layout has a y column)
+    out->base = reinterpret_cast<uint8_t *>(rec.ranges[0].p);  // the handle aesw_columns_free looks the arena up by
     for (auto &r : rec.ranges) out->bytes += r.bytes;
     out->candidates = total_cands;
     out->chosen = 0;

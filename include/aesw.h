@@ -243,6 +243,7 @@ typedef struct aesw_columns {
     float probe_us;      /* store-pattern emulation over the set as placed, microseconds per pass */
     float fill_us;       /* a linear fill of the same bytes */
 } aesw_columns;
+/* with_key_slab: 0 = encrypt columns only, 1 = + n key slabs, 2 = the n key slabs alone (for aesw_key_schedule_witness_device) */
 int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab, int with_ct,
                        aesw_columns *out);
 int aesw_columns_free(aesw_ctx *ctx, aesw_columns *cols);

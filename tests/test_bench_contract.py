@@ -45,3 +45,35 @@ def test_watchdog_exits_non_zero(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, timeout=60)
     assert out.returncode == 3
     assert "phase 'gather' timed out" in out.stdout
+
+
+def test_main_never_rebinds_its_long_lived_names():
+    """bench.py's main() is one long function; a loop variable that shadows the argparse namespace (`a`), the line, the context
+    ... breaks code hundreds of lines further down and loses the headline (it happened once, caught on the GPU box).  No for /
+    comprehension / with / except target and no later assignment in main() may rebind these names."""
+    import ast
+    tree = ast.parse((ROOT / "bench.py").read_text())
+    main = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    protected = {"a", "line", "ctx", "pkg", "rank", "world", "use_arena", "layout", "pbk", "extras"}
+    first_assign = {}
+    bad = []
+    for node in ast.walk(main):
+        targets = []
+        if isinstance(node, (ast.For, ast.comprehension)):
+            targets = [node.target]
+        elif isinstance(node, ast.With):
+            targets = [i.optional_vars for i in node.items if i.optional_vars is not None]
+        elif isinstance(node, ast.ExceptHandler) and node.name in protected:
+            bad.append((node.name, node.lineno))
+        elif isinstance(node, ast.Assign):
+            for t in node.targets:
+                for n in ast.walk(t):
+                    if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store) and n.id in protected:
+                        first_assign.setdefault(n.id, []).append(n.lineno)
+        for t in targets:
+            for n in ast.walk(t):
+                if isinstance(n, ast.Name) and n.id in protected:
+                    bad.append((n.id, n.lineno))
+    assert not bad, bad
+    for name, lines in first_assign.items():
+        assert len(lines) == 1 or name in ("ctx",), (name, lines)  # assigned exactly once

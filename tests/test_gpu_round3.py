@@ -205,3 +205,19 @@ def test_rescheduling_a_key_waits_for_launches_still_reading_the_old_one(pkg, or
         assert np.array_equal(out_a.z.cpu().numpy(), ea.z)
         assert np.array_equal(out_b.ct.cpu().numpy(), eb.ct)
     c.close()
+
+
+def test_key_only_arena(ctx, pkg, oracle):
+    """aesw_columns_alloc(with_key_slab = 2): the key-schedule witness alone in a (probed) arena, filled by key_kernel."""
+    import torch
+    rng = np.random.default_rng(55)
+    n = (1 << 16) + 9
+    keys = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    a = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, key_only=True)
+    assert a.x.numel() == 0 and a.y.numel() == 0 and a.z.numel() == 0 and ctx.last_arena["candidates"] >= 1
+    got = ctx.key_schedule_witness(torch.from_numpy(keys).cuda(), layout=pkg.LAYOUT_PACKED, want_rk=False, out=a.key)
+    torch.cuda.synchronize()
+    k = oracle.key_schedule_witness(keys, layout=ol.PACKED)
+    for c in ("w", "kx", "ky", "kz"):
+        assert np.array_equal(getattr(got, c).cpu().numpy(), getattr(k, c)), c
+    ctx.free_columns(a)
