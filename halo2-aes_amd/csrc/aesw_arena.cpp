@@ -151,6 +151,9 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     pp.xcd_mode = ctx->xcd_remap;
     // two timed passes of a 2^20-block set; proportionally more for smaller batches (short launches time noisily)
     const int passes = n >= ((uint64_t)1 << 20) ? 2 : (int)std::min<uint64_t>(32, (((uint64_t)1 << 21) + n - 1) / n);
+    // "as fast as a linear fill": the two levels are 0.98 - 1.02 and >= 1.05 of the fill at 2^18 blocks and more; a shorter launch
+    // carries its ramp and tail (2^16 blocks: 1.04 - 1.06 at best), so the bar is lower there and the per-column search is not run
+    const float accept = n >= ((uint64_t)1 << 18) ? 1.025f : 1.065f;
     uint32_t total_cands = 0;
     struct Placement {
         std::vector<Range> ranges;
@@ -229,7 +232,7 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
                 const float ratio = f / ref_fill;
                 if (!best.p || f < best_probe * passes * 1e-3f) { best = r; best_probe = f * 1e3f / passes; }
                 best_fill = ref_fill * 1e3f / passes;
-                if (ratio <= 1.025f) break;  // the many-front pattern as fast as a linear fill (the two levels are 0.98 - 1.02 and >= 1.05): as good as it gets
+                if (ratio <= accept) break;  // the many-front pattern as fast as a linear fill: as good as it gets
             }
             for (size_t i = 0; i < losers.size(); ++i)
                 if (losers[i].p == best.p) { losers.erase(losers.begin() + (long)i); break; }
@@ -253,7 +256,7 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     // search places the columns one at a time (the whole-set losers stay held meanwhile) and the better of the two is kept
     Placement pl = search(ctx->arena_unit == 1 ? 1 : 0);
     if (pl.rc != AESW_OK) return pl.rc;
-    if (ctx->arena_unit == 2 && pl.probe_us > 1.025f * pl.fill_us) {
+    if (ctx->arena_unit == 2 && n >= ((uint64_t)1 << 18) && pl.probe_us > accept * pl.fill_us) {
         Placement alt = search(1);
         if (alt.rc == AESW_OK && alt.probe_us / alt.fill_us < pl.probe_us / pl.fill_us) std::swap(pl, alt);
         for (auto &r : alt.ranges) losers.push_back(r);  // the search that lost (or failed half-way: already handed over)
