@@ -93,7 +93,9 @@ class Runner:
         if key_slab:
             per_set += (96 + sum(pkg.key_column_stride(layout, c) for c in range(3))) * n
         self.out_bytes_per_step = per_set
-        self.nsets = max(2, min(8, -(-(640 << 20) // per_set)))
+        # the ring exists so that a step never rewrites lines the 256 MiB Infinity Cache still holds from the previous one: sets
+        # are rotated until 640 MB lie between two writes of the same byte; a set that is that large by itself needs no partner
+        self.nsets = 1 if per_set >= (640 << 20) else max(2, min(8, -(-(640 << 20) // per_set)))
         # arena: one device allocation per set with aligned column bases (aesw_columns_alloc); else one tensor per column
         self.sets, self.arena_info = [], []
         for _ in range(self.nsets):
