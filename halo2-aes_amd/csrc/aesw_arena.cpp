@@ -111,7 +111,6 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     const int size_of7[7] = {0, 1, 2, 4, 5, 6, 7};  // probe column c (x y z w kx ky kz) -> index into size[] / off[]
     const size_t MiB2 = (size_t)2 << 20;
     auto round2m = [&](uint64_t v) { return (size_t)((v + MiB2 - 1) / MiB2 * MiB2); };
-    auto release = [](const Range &r) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); };
     auto build = [&](int kind, size_t bytes, Range *r) -> int {
         static const size_t chunk_of[4] = {(size_t)8 << 20, (size_t)2 << 20, (size_t)32 << 20, (size_t)4 << 20};
         if (kind % 5 == 0) {
