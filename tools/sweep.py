@@ -53,7 +53,11 @@ for v in variants:
     ctxs.append(c)
 n = 1 << log2n
 pbk = workload == "c2"
-runners = [bench.Runner(pkg, c, torch, n, pbk, layout, pbk, 1234) for c in ctxs[:1]]
+# the shared output columns live in a probed arena (round 3: placement decides 10 - 20 % of a launch; on memory chosen by
+# measurement the options are compared at the rate the product runs at).  AESW_SWEEP_ARENA=0: plain tensors as in rounds 1 - 2
+import os  # noqa: E402
+runners = [bench.Runner(pkg, c, torch, n, pbk, layout, pbk, 1234, arena=os.environ.get("AESW_SWEEP_ARENA", "1") != "0") for c in ctxs[:1]]
+print("arena:", runners[0].arena_info)
 # share one runner's buffers across contexts: only the ctx handle differs
 base = runners[0]
 results = {i: [] for i in range(len(variants))}
