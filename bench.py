@@ -684,52 +684,10 @@ def main():
             del full
             return dt
 
-        try:
-            dog.arm("gather warm-up (RCCL communicator + peer channel set-up)", 120.0)
-            timed_gather(runner.sets[0], n)
-            dog.arm("gather", 60.0)
-            dt = timed_gather(runner.sets[0], n)
-            dog.disarm()
-            if rank == 0:
-                line["gather"] = {"seconds": dt, "GBps_into_root": (world - 1) * n * sum(strides) / dt / 1e9,
-                                  "path": pkg.sharding.last_gather_path,
-                                  "note": "per-rank column ranges gathered on rank 0, outside `value`"}
-        except Exception as e:
-            dog.disarm()
-            failed.append("gather")
-            if rank == 0:
-                line["gather"] = {"error": str(e)}
+        # Order of the tail: configs[4] first (every rank for itself: barriers and two small all-reduces are its only collectives),
+        # then the exchange steps whose RCCL leg has never run with real ranks -- if one of those stalls, the watchdog's
+        # line already carries c4.
         if not a.no_extras:
-            # BASELINE configs[3]: 2^24 blocks over 8 GPUs = 2^21 per GPU, columns gathered on GPU 0 (never `value`)
-            try:
-                runner.close()
-                del runner
-                torch.cuda.empty_cache()
-                n3 = 1 << (a.c3_log2_blocks or 21)
-                dog.arm("c3 generation", 120.0)
-                r3 = Runner(pkg, ctx, torch, n3, False, layout, False, SEED + 11 + rank, arena=use_arena)
-                steps3 = 10
-                w3, ms3, _ = r3.run(steps3, 2, not a.no_graph, barrier)
-                t3 = torch.tensor([w3, ms3], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-                dist.all_reduce(t3, op=dist.ReduceOp.MAX)
-                dog.arm("c3 gather", 120.0)
-                dt3 = timed_gather(r3.sets[0], n3)
-                dog.disarm()
-                if rank == 0:
-                    line["c3"] = {"workload": "2^%d blocks per GPU x %d GPUs, one shared key, %s columns" % (a.c3_log2_blocks or 21, world, a.layout),
-                                  "blocks_total": n3 * world, "blocks_per_s": n3 * world * steps3 / float(t3[0]),
-                                  "launch_ms": float(t3[1]),
-                                  "achieved_GBps_per_gpu": BYTES_SHARED * n3 / (float(t3[1]) * 1e-3) / 1e9,
-                                  "gather_seconds": dt3, "gather_GBps_into_root": (world - 1) * n3 * sum(strides) / dt3 / 1e9,
-                                  "gather_path": pkg.sharding.last_gather_path,
-                                  "note": "generation and gather timed separately; the gather is bound by the root's xGMI ingest"}
-                r3.close()
-                del r3
-            except Exception as e:
-                dog.disarm()
-                failed.append("c3")
-                if rank == 0:
-                    line["c3"] = {"error": str(e)}
             # BASELINE configs[4] at N > 1: every rank streams its own shard to its own host over its own PCIe link (DESIGN 7:
             # the right delivery path -- no gather), kernel + async D2H overlapped with a cheap consumer; ranks timed between
             # barriers, MAX over ranks.  Consumer to match: region.assign_advice, src/aes128.rs:176-192.
@@ -780,6 +738,52 @@ def main():
                 failed.append("c4")
                 if rank == 0:
                     line["c4"] = {"error": str(e)}
+        try:
+            dog.arm("gather warm-up (RCCL communicator + peer channel set-up)", 120.0)
+            timed_gather(runner.sets[0], n)
+            dog.arm("gather", 60.0)
+            dt = timed_gather(runner.sets[0], n)
+            dog.disarm()
+            if rank == 0:
+                line["gather"] = {"seconds": dt, "GBps_into_root": (world - 1) * n * sum(strides) / dt / 1e9,
+                                  "path": pkg.sharding.last_gather_path,
+                                  "note": "per-rank column ranges gathered on rank 0, outside `value`"}
+        except Exception as e:
+            dog.disarm()
+            failed.append("gather")
+            if rank == 0:
+                line["gather"] = {"error": str(e)}
+        if not a.no_extras:
+            # BASELINE configs[3]: 2^24 blocks over 8 GPUs = 2^21 per GPU, columns gathered on GPU 0 (never `value`)
+            try:
+                runner.close()
+                del runner
+                torch.cuda.empty_cache()
+                n3 = 1 << (a.c3_log2_blocks or 21)
+                dog.arm("c3 generation", 120.0)
+                r3 = Runner(pkg, ctx, torch, n3, False, layout, False, SEED + 11 + rank, arena=use_arena)
+                steps3 = 10
+                w3, ms3, _ = r3.run(steps3, 2, not a.no_graph, barrier)
+                t3 = torch.tensor([w3, ms3], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+                dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+                dog.arm("c3 gather", 120.0)
+                dt3 = timed_gather(r3.sets[0], n3)
+                dog.disarm()
+                if rank == 0:
+                    line["c3"] = {"workload": "2^%d blocks per GPU x %d GPUs, one shared key, %s columns" % (a.c3_log2_blocks or 21, world, a.layout),
+                                  "blocks_total": n3 * world, "blocks_per_s": n3 * world * steps3 / float(t3[0]),
+                                  "launch_ms": float(t3[1]),
+                                  "achieved_GBps_per_gpu": BYTES_SHARED * n3 / (float(t3[1]) * 1e-3) / 1e9,
+                                  "gather_seconds": dt3, "gather_GBps_into_root": (world - 1) * n3 * sum(strides) / dt3 / 1e9,
+                                  "gather_path": pkg.sharding.last_gather_path,
+                                  "note": "generation and gather timed separately; the gather is bound by the root's xGMI ingest"}
+                r3.close()
+                del r3
+            except Exception as e:
+                dog.disarm()
+                failed.append("c3")
+                if rank == 0:
+                    line["c3"] = {"error": str(e)}
         dog.arm("shutdown", 60.0)
         try:
             # a phase that raised on ANY rank fails the whole job: agree on it before leaving
