@@ -20,7 +20,7 @@ pkg = ge.load_package()
 orc = ol.Oracle()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-threads = min(64, os.cpu_count() or 8)
+threads = min(16, os.cpu_count() or 8)
 t0 = time.time()
 for it in range(iters):
     layout = int(rng.integers(0, 3))
@@ -32,18 +32,23 @@ for it in range(iters):
     ctx.set_option("store_mode", int(rng.integers(0, 3)))
     if rng.integers(0, 4) == 0:
         ctx.set_option("grid_cap", int(rng.integers(1, 2048)))
+    ctx.set_option("xcd_remap", int(rng.choice([0, 1, 1, 2, 7, 64, 1000, 100000])))
+    arena = bool(rng.integers(0, 2))  # round 3: output columns in a probed arena (virtual-memory backed) or in plain tensors
+    ctx.set_option("arena_probe", int(rng.integers(1, 4)))
+    ctx.set_option("arena_unit", int(rng.integers(0, 3)))
     pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
     keys = rng.integers(0, 256, (n, 16), dtype=np.uint8)
     dpt = torch.from_numpy(pt).cuda()
+    out = ctx.alloc_columns(n, layout, want_ct=True, key_slab=keymode == 2) if arena else None
     if keymode == 0:
         ctx.schedule_key(torch.from_numpy(keys[0]).cuda(), layout=layout, key_slab=False)
-        got = ctx.encrypt_witness(dpt, None, layout=layout, want_ct=True)
+        got = ctx.encrypt_witness(dpt, None, layout=layout, want_ct=True, out=out)
         kh = keys[0]
     elif keymode == 1:
-        got = ctx.encrypt_witness(dpt, torch.from_numpy(keys[0]).cuda(), layout=layout, want_ct=True)
+        got = ctx.encrypt_witness(dpt, torch.from_numpy(keys[0]).cuda(), layout=layout, want_ct=True, out=out)
         kh = keys[0]
     else:
-        got = ctx.encrypt_witness(dpt, torch.from_numpy(keys).cuda(), layout=layout, want_ct=True, key_slab=True)
+        got = ctx.encrypt_witness(dpt, torch.from_numpy(keys).cuda(), layout=layout, want_ct=True, key_slab=True, out=out)
         kh = keys
     torch.cuda.synchronize()
     exp = orc.encrypt_witness(pt, kh, layout=layout, threads=threads)
