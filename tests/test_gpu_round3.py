@@ -221,3 +221,18 @@ def test_key_only_arena(ctx, pkg, oracle):
     for c in ("w", "kx", "ky", "kz"):
         assert np.array_equal(getattr(got, c).cpu().numpy(), getattr(k, c)), c
     ctx.free_columns(a)
+
+
+def test_arena_from_plain_c(pkg, tmp_path):
+    """examples/aesw_arena.c: aesw_columns_alloc -> aesw_encrypt_witness_device -> hipMemcpy back, from plain C, equals the
+    host-pointer entry point byte for byte; the struct reports the search and is cleared by aesw_columns_free."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "aesw_arena"
+    lib_dir = root / "halo2-aes_amd"
+    subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", str(root / "include"), "-I", "/opt/rocm/include",
+                    str(root / "examples" / "aesw_arena.c"), "-o", str(exe), "-L", str(lib_dir), "-laesw", "-L", "/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe), "17"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok") and "candidate backings timed" in out.stdout, out.stdout
