@@ -94,8 +94,78 @@ static int spacing_mode(int stride) {
     return 0;
 }
 
+// "map" mode: the whole device memory as 256 MiB tiles in the order the driver hands them out; the one-column many-front
+// pattern against a linear fill on each, twice.  '.' = pattern within 8 % of the fill, '#' = slower, digits = the ratio's
+// first decimal beyond 1.0 when the two repeats disagree.
+static int map_mode(int stride, size_t tile_mib, int max_tiles) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const size_t tile = tile_mib << 20;
+    size_t free_b = 0, total_b = 0;
+    CK(hipMemGetInfo(&free_b, &total_b));
+    int nt = (int)((free_b - ((size_t)6 << 30)) / tile);
+    if (max_tiles > 0 && max_tiles < nt) nt = max_tiles;
+    void *va = nullptr;
+    CK(hipMemAddressReserve(&va, tile * nt, 0, nullptr, 0));
+    int made = 0;
+    for (int i = 0; i < nt; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, tile, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+        CK(hipMemMap((uint8_t *)va + (size_t)i * tile, tile, 0, h, 0));
+        CK(hipMemRelease(h));
+        ++made;
+    }
+    CK(hipMemSetAccess(va, tile * made, &acc, 1));
+    hipEvent_t e0, e1, e2;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    const uint32_t tb = (uint32_t)(tile / stride / 16 * 16);
+    printf("%d tiles of %zu MiB (%.1f GiB of %.1f GiB free), stride %d\n", made, tile_mib, made * (double)tile / (1 << 30), free_b / (double)(1 << 30), stride);
+    std::vector<float> r[2];
+    for (int rep = 0; rep < 2; ++rep) {
+        r[rep].resize(made);
+        for (int i = 0; i < made; ++i) {
+            uint8_t *b = (uint8_t *)va + (size_t)i * tile;
+            hipLaunchKernelGGL(k_fronts, dim3(tb / 16), dim3(64), 0, 0, b, tb, stride);
+            CK(hipEventRecord(e0));
+            for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_fronts, dim3(tb / 16), dim3(64), 0, 0, b, tb, stride);
+            CK(hipEventRecord(e1));
+            for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)tb * stride + 4095) / 4096)), dim3(256), 0, 0, b, (size_t)tb * stride);
+            CK(hipEventRecord(e2));
+            CK(hipEventSynchronize(e2));
+            float f, l;
+            CK(hipEventElapsedTime(&f, e0, e1));
+            CK(hipEventElapsedTime(&l, e1, e2));
+            r[rep][i] = f / l;
+        }
+    }
+    int nfast = 0;
+    for (int i = 0; i < made; ++i) {
+        const bool a = r[0][i] <= 1.08f, b2 = r[1][i] <= 1.08f;
+        nfast += a && b2;
+        if (i % 64 == 0) printf("\n%5d  ", i);
+        if (a == b2) putchar(a ? '.' : '#');
+        else putchar('0' + (int)std::min(9.0f, std::max(0.0f, (std::max(r[0][i], r[1][i]) - 1.0f) * 10)));
+    }
+    printf("\n%d of %d tiles run the pattern within 8 %% of their fill in both repeats\n", nfast, made);
+    int hist[2][12] = {};
+    for (int rep = 0; rep < 2; ++rep)
+        for (int i = 0; i < made; ++i) hist[rep][std::min(11, std::max(0, (int)((r[rep][i] - 0.96f) / 0.02f)))]++;
+    for (int rep = 0; rep < 2; ++rep) {
+        printf("repeat %d, ratio histogram from 0.96 in steps of 0.02:", rep);
+        for (int b = 0; b < 12; ++b) printf(" %d", hist[rep][b]);
+        printf("\n");
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "spacing")) return spacing_mode(argc > 2 ? atoi(argv[2]) : 1360);
+    if (argc > 1 && !strcmp(argv[1], "map")) return map_mode(argc > 2 ? atoi(argv[2]) : 1360, argc > 3 ? (size_t)atoi(argv[3]) : 256, argc > 4 ? atoi(argv[4]) : 0);
     const int N = argc > 1 ? atoi(argv[1]) : 16;
     const int stride = argc > 2 ? atoi(argv[2]) : 1360;
     const uint32_t nblk = 1u << 20;
