@@ -65,8 +65,10 @@ def parse():
                     help="N>1: blocks EVERY rank streams to its own host in the configs[4] leg (2^24 over 8 GPUs = 2^21 per GPU)")
     ap.add_argument("--arena", choices=["auto", "on", "off"], default="auto",
                     help="output columns of a set in ONE device allocation (aesw_columns_alloc) instead of separate tensors")
-    ap.add_argument("--gather-path", choices=["auto", "torch"], default="auto",
-                    help="N>1: 'torch' forces the torch.distributed point-to-point gather instead of the C ABI's RCCL gather")
+    ap.add_argument("--gather-path", choices=["torch", "cabi"], default="torch",
+                    help="N>1: what the timed `gather` and `c3` phases use: torch.distributed point-to-point send/recv (RCCL through torch's "
+                         "communicator: the default, a path that has run on hardware) or the C ABI's own RCCL gather (aesw_gather_columns_device: "
+                         "never run with more than one real rank, DESIGN 7); the C ABI's gather is ALSO run as the last phase (`gather_cabi`)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of a hipGraph")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to aesw_set_option")
@@ -671,13 +673,13 @@ def main():
         strides = [pkg.column_stride(layout, c) for c in range(3)]
         failed = []  # phases of the N>1 tail that raised on THIS rank: the process then exits non-zero (after printing)
 
-        def timed_gather(wset, nblk):
+        def timed_gather(wset, nblk, cabi=a.gather_path == "cabi"):
             gcols = [wset.x, wset.y, wset.z] if a.backend == "nccl" else [c.cpu() for c in (wset.x, wset.y, wset.z)]
             torch.cuda.synchronize()
             dist.barrier()
             t0 = time.perf_counter()
             full = pkg.sharding.gather_columns(gcols, [nblk] * world, strides, dst=0, ctx=ctx if a.backend == "nccl" else None,
-                                               force_torch=a.gather_path == "torch")
+                                               force_torch=not cabi)
             torch.cuda.synchronize()
             dist.barrier()
             dt = time.perf_counter() - t0
@@ -784,6 +786,27 @@ def main():
                 failed.append("c3")
                 if rank == 0:
                     line["c3"] = {"error": str(e)}
+        if not a.no_extras and a.backend == "nccl" and a.gather_path != "cabi":
+            # LAST, because it is the one step that has never run with real ranks: the C ABI's own RCCL gather (what a host without
+            # torch calls) over 2^20-block columns.  Everything measured so far is already in the line: a stall
+            # here ends the job through the watchdog (status 3) with that line printed; an exception is recorded and is not fatal.
+            try:
+                dog.arm("gather_cabi warm-up (second RCCL communicator beside torch's: ncclCommInitRank + peer channels)", 120.0)
+                ng = 1 << 20
+                wg = ctx.alloc_witness(ng, layout)
+                timed_gather(wg, ng, cabi=True)
+                dog.arm("gather_cabi", 60.0)
+                dtg = timed_gather(wg, ng, cabi=True)
+                dog.disarm()
+                if rank == 0:
+                    line["gather_cabi"] = {"seconds": dtg, "GBps_into_root": (world - 1) * ng * sum(strides) / dtg / 1e9,
+                                           "path": pkg.sharding.last_gather_path, "blocks_per_rank": ng,
+                                           "note": "aesw_gather_columns_device: ncclSend / ncclRecv in one group on the caller's stream"}
+                del wg
+            except Exception as e:
+                dog.disarm()
+                if rank == 0:
+                    line["gather_cabi"] = {"error": str(e), "fatal": False}
         dog.arm("shutdown", 60.0)
         try:
             # a phase that raised on ANY rank fails the whole job: agree on it before leaving
