@@ -676,7 +676,7 @@ __device__ __forceinline__ uint32_t advice_cell(const AssembleParams &a, uint32_
     if (set == 0 && row < KEY_ROWS) {
         const uint8_t *kc = c == 0 ? a.kx : c == 1 ? a.ky : a.kz;
         if (!kc) return 0u;
-        const int idx = a.packed ? a.pidx[3 * AES_ROWS + c * KEY_ROWS + row] : (int)row;
+        const int idx = a.packed ? packed_index_key((int)c, (int)row) : (int)row;
         return idx >= 0 ? kc[idx] : 0u;
     }
     const uint64_t base = set == 0 ? KEY_ROWS : 0;
@@ -689,7 +689,7 @@ __device__ __forceinline__ uint32_t advice_cell(const AssembleParams &a, uint32_
     if (b >= a.n_blocks) return 0u;
     const uint8_t *sc = c == 0 ? a.x : c == 1 ? a.y : a.z;
     const uint32_t stride = c == 0 ? a.sx : c == 1 ? a.sy : a.sz;
-    const int idx = a.packed ? a.pidx[c * AES_ROWS + r] : (int)r;
+    const int idx = a.packed ? packed_index_enc((int)c, (int)r) : (int)r;
     return idx >= 0 ? sc[b * stride + idx] : 0u;
 }
 
@@ -703,7 +703,7 @@ __device__ __forceinline__ uint32_t advice_cell(const AssembleParams &a, uint32_
 // below, byte for byte the same output.  So the divisions were not what held the one-shot form back in round 2: a piece is a
 // chain of three dependent loads (packed-index table -> slab byte -> LUT), a one-shot workgroup has nothing else in flight,
 // and 2 048 resident workgroups x 4 KiB / (that chain's latency) is the rate; expand_fr, whose chain is two loads long, reaches
-// 7.3 TB/s in the same geometry.  Kept as option "assemble_geometry" 1, tested; the striding kernel stays the default.
+// 7.3 TB/s in the same geometry.  Kept as option "assemble_geometry" 1, tested; superseded by the aligned form below.
 template <int NT>
 __global__ void __launch_bounds__(256) assemble_fr_oneshot_kernel(const AssembleParams a) {
     const uint32_t piece = blockIdx.x * 256 + threadIdx.x;  // 16-byte piece of the segment: 2 per row
@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(256) assemble_fr_oneshot_kernel(const Assemble
         row = r;
         const uint8_t *kc = c == 0 ? a.kx : c == 1 ? a.ky : a.kz;
         if (kc) {
-            const int idx = a.packed ? a.pidx[3 * AES_ROWS + c * KEY_ROWS + r] : (int)r;
+            const int idx = a.packed ? packed_index_key((int)c, (int)r) : (int)r;
             if (idx >= 0) v = kc[idx];
         }
     } else {
@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(256) assemble_fr_oneshot_kernel(const Assemble
             if (b < a.n_blocks) {
                 const uint8_t *sc = c == 0 ? a.x : c == 1 ? a.y : a.z;
                 const uint32_t stride = c == 0 ? a.sx : c == 1 ? a.sy : a.sz;
-                const int idx = a.packed ? a.pidx[c * AES_ROWS + r] : (int)r;
+                const int idx = a.packed ? packed_index_enc((int)c, (int)r) : (int)r;
                 if (idx >= 0) v = sc[b * stride + idx];
             }
         }
@@ -744,6 +744,51 @@ __global__ void __launch_bounds__(256) assemble_fr_oneshot_kernel(const Assemble
     const u32x4 *lut = reinterpret_cast<const u32x4 *>(a.fr_lut);  // 8 KiB, L1 / L2 resident
     u32x4 *out = reinterpret_cast<u32x4 *>(a.out) + (((uint64_t)blockIdx.z << a.k) + row) * 2 + (piece & 1);
     gstore<NT>(out, lut[v * 2 + (piece & 1)]);
+}
+
+// Geometry 2 / 3 (the default): the same one-shot workgroups cut on the OUTPUT instead -- a workgroup writes PIECES aligned
+// 4 KiB chunks (128 rows each) of one column, expand_fr's GEO 1 -- at the price of one 32-bit division by AES_ROWS per piece
+// (a multiply-high; K <= 30 is checked on the host).  The slab index comes from packed_index_enc/_key instead of the
+// table, everything that depends on the column only is scalar, and with PIECES = 2 a thread has two independent
+// byte -> LUT -> store chains in flight.  Measured (tools/asm_geo.py, N = 5; TB/s written, striding / geometry 1 / 2 / 3 /
+// expand_fr over as many bytes): K = 17: 4.6 / 4.3 / 5.1 / 5.6 / 5.7; K = 20: 5.2 / 5.1 / 6.1 / 6.3 / 7.0;
+// K = 22: 4.2 / 5.4 / 6.2 / 6.7 / 7.1.  Four chunks per workgroup are slower again (5.8).
+template <int NT, int PIECES>
+__global__ void __launch_bounds__(256) assemble_fr_aligned_kernel(const AssembleParams a) {
+    const uint32_t col = a.col_first + blockIdx.y;
+    const uint32_t n_adv = 3 * a.n_sets;
+    const bool words = col == n_adv;
+    const uint32_t set = col / 3, c = col - 3 * set;
+    const uint32_t base = (!words && set == 0) ? KEY_ROWS : 0;
+    const uint8_t *kc = c == 0 ? a.kx : c == 1 ? a.ky : a.kz;
+    const uint8_t *sc = c == 0 ? a.x : c == 1 ? a.y : a.z;
+    const uint32_t stride = c == 0 ? a.sx : c == 1 ? a.sy : a.sz;
+    const uint64_t cap = set == 0 ? a.cap0 : a.capn;
+    const uint64_t b0 = set == 0 ? 0 : a.cap0 + (uint64_t)(set - 1) * a.capn;
+    const uint32_t half = threadIdx.x & 1;
+    uint32_t row[PIECES], v[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+        row[j] = ((blockIdx.x * PIECES + j) * 256 + threadIdx.x) >> 1;
+        v[j] = 0;
+        if (words) {
+            if (row[j] < WORDS_ROWS && a.kw) v[j] = a.kw[row[j]];
+        } else if (row[j] < base) {
+            const int idx = a.packed ? packed_index_key((int)c, (int)row[j]) : (int)row[j];
+            if (kc && idx >= 0) v[j] = kc[idx];
+        } else {
+            const uint32_t rr = row[j] - base, bi = rr / AES_ROWS, r = rr - bi * AES_ROWS;
+            const int idx = a.packed ? packed_index_enc((int)c, (int)r) : (int)r;
+            if (bi < cap && b0 + bi < a.n_blocks && idx >= 0) v[j] = sc[(b0 + bi) * stride + idx];
+        }
+    }
+    const u32x4 *lut = reinterpret_cast<const u32x4 *>(a.fr_lut);
+    u32x4 *out = reinterpret_cast<u32x4 *>(a.out) + ((uint64_t)blockIdx.y << (a.k + 1)) + half;
+    u32x4 f[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) f[j] = lut[v[j] * 2 + half];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) gstore<NT>(out + (uint64_t)row[j] * 2, f[j]);
 }
 
 // (A one-shot geometry like expand_fr's was tried for the cell-indexed form below in round 2 and is 9x SLOWER: a piece here is a chain of
@@ -1000,6 +1045,12 @@ hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t
     return hipGetLastError();
 }
 
+template <int NT>
+static void launch_assemble_aligned(int lg, dim3 grid, hipStream_t s, const AssembleParams &p) {
+    if (lg == 0) hipLaunchKernelGGL((assemble_fr_aligned_kernel<NT, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((assemble_fr_aligned_kernel<NT, 2>), grid, dim3(256), 0, s, p);
+}
+
 hipError_t launch_assemble(const AssembleParams &p0, bool as_fr, int nt, hipStream_t s) {
     AssembleParams p = p0;
     {   // capacities of aes_callable (src/aes128.rs:303-325): computed here so that no kernel divides
@@ -1015,6 +1066,16 @@ hipError_t launch_assemble(const AssembleParams &p0, bool as_fr, int nt, hipStre
         if (nt == 2) hipLaunchKernelGGL((assemble_fr_oneshot_kernel<2>), grid, dim3(256), 0, s, p);
         else if (nt == 1) hipLaunchKernelGGL((assemble_fr_oneshot_kernel<1>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((assemble_fr_oneshot_kernel<0>), grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    if (as_fr && p.geometry >= 2 && p.col_count > 0 && p.k >= 8 && p.k <= 30 && p.col_count <= 65535) {
+        // a workgroup writes 1 or 2 aligned 4 KiB chunks (geometry 2, 3): 2^k rows x 2 pieces / (256 x chunks) workgroups;
+        // smaller or larger K fall through to the striding kernel
+        const int lg = p.geometry - 2;
+        const dim3 grid(1u << (p.k - 7 - lg), p.col_count);
+        if (nt == 2) launch_assemble_aligned<2>(lg, grid, s, p);
+        else if (nt == 1) launch_assemble_aligned<1>(lg, grid, s, p);
+        else launch_assemble_aligned<0>(lg, grid, s, p);
         return hipGetLastError();
     }
     const uint64_t cells = (uint64_t)p.col_count << p.k;

@@ -431,6 +431,37 @@ inline void key_assigned_mask(int col, uint8_t mask[KEY_ROWS]) {
     }
 }
 
+// Closed forms of the dense-row -> packed-index maps (the prefix counts of encrypt_assigned_mask / key_assigned_mask
+// above; -1 = the row is never assigned in that column).  The assemble kernels use these instead of a table so that a
+// cell is a chain of two loads (slab byte -> Fr LUT), not three; tests/test_lane_model.py checks them row by row against
+// the masks.
+AESW_HD int packed_index_enc(int c, int r) {
+    if (c == 0) return r;
+    if (r < 16) return -1;
+    if (r < 32) return r - 16;
+    if (r >= 1328) {  // round 10: S-box rows (x, y), then the last AddRoundKey (x, y, z)
+        if (r < 1344) return c == 1 ? 1024 + (r - 1328) : -1;
+        return (c == 1 ? 1040 : 592) + (r - 1344);
+    }
+    const int R1 = (r - 32) / 144, q = (r - 32) - 144 * R1;  // rounds 1..9: 112 y and 64 z per round
+    const int base = 16 + (c == 1 ? 112 : 64) * R1;
+    if (q < 16) return c == 1 ? base + q : -1;                       // SubBytes
+    if (q >= 128) return base + (c == 1 ? 96 : 48) + (q - 128);      // AddRoundKey
+    const int k = (q - 16) / 7, t = (q - 16) - 7 * k;                 // MixColumns record k, row t of 7
+    if (t >= 4) return c == 1 ? base + 18 + 5 * k + (t - 4) : base + 3 * k + (t - 4);
+    if (c == 2) return -1;
+    const int m = k & 3;  // the two products of MIX row m sit at t = m, m + 1 (m = 3: t = 0, 3)
+    const int first = m == 3 ? 0 : m, second = m == 3 ? 3 : m + 1;
+    return t == first ? base + 16 + 5 * k : t == second ? base + 17 + 5 * k : -1;
+}
+
+AESW_HD int packed_index_key(int c, int r) {
+    if (c == 0) return r;
+    const int rho = r / 40, j = r - 40 * rho;
+    if (c == 1) return j < 24 ? 24 * rho + j : -1;
+    return (j >= 4 && j < 24) ? 20 * rho + (j - 4) : -1;
+}
+
 // Fixed data for keygen: which chip's selector is enabled on
 // each slab row, as the Tag of its lookup (src/table.rs:10-16): 0 none (plain
 // copy / assign regions), 1 U8 range, 2 Xor, 3 Sbox, 4 GfMul2, 5 GfMul3.

@@ -201,6 +201,10 @@ extern "C" void lane_model_masks(int col, uint8_t *enc_mask, uint8_t *key_mask) 
     key_assigned_mask(col, key_mask);
 }
 
+extern "C" int lane_model_packed_index(int key, int col, int row) {
+    return key ? packed_index_key(col, row) : packed_index_enc(col, row);
+}
+
 // window geometry, for the tests
 extern "C" void lane_model_window(int layout, int col, int out[6]) {
     auto fill = [&](auto w) {

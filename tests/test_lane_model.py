@@ -100,6 +100,15 @@ def test_masks_match_oracle(model, oracle):
         assert np.array_equal(km, oracle.key_assigned_mask(col))
 
 
+def test_closed_form_packed_index_matches_the_masks(model, oracle):
+    """assemble's arithmetic dense-row -> packed-index map == the prefix count of the oracle's assigned masks."""
+    for col in range(3):
+        for key, mask in ((0, oracle.assigned_mask(col)), (1, oracle.key_assigned_mask(col))):
+            want = np.where(mask.astype(bool), np.cumsum(mask.astype(np.int64)) - 1, -1)
+            got = np.array([model.lane_model_packed_index(key, col, r) for r in range(len(mask))])
+            assert np.array_equal(got, want), (col, key, np.flatnonzero(got != want)[:8])
+
+
 def test_values_mask_matches_oracle(model, oracle):
     """The VALUES layout keeps exactly the cells a chip closure computes (y: S-box / mul rows, z: xor rows)."""
     for col in range(3):

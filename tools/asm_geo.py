@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""assemble_kernel as Fr cells: striding workgroups (assemble_geometry 0) vs the division-free one-shot grid (1, round 3).
-K = 20, N = 5 (16 columns x 2^20 cells x 32 B = 512 MiB), full capacity; both outputs compared byte for byte."""
+"""The Fr form of assemble: striding workgroups (assemble_geometry 0), the division-free one-shot grid (1) and one-shot
+workgroups on one / two aligned 4 KiB chunks of the output (2 / 3 = the default), with expand_fr over as many bytes as the
+yardstick.  K from argv (default 20), N = 5 (16 columns x 2^K cells x 32 B), full capacity; all outputs compared byte for byte."""
 import statistics
 import sys
 from pathlib import Path
@@ -10,7 +11,7 @@ import torch  # noqa: E402
 import __graft_entry__ as ge  # noqa: E402
 ge.build()
 pkg = ge.load_package()
-k, n_sets = 20, 5
+k, n_sets = (int(sys.argv[1]) if len(sys.argv) > 1 else 20), 5
 ctx = pkg.Context(0)
 nn = pkg.block_capacity(k, n_sets)
 pt = torch.randint(0, 256, (nn, 16), dtype=torch.uint8, device="cuda")
@@ -18,9 +19,9 @@ key = torch.randint(0, 256, (16,), dtype=torch.uint8, device="cuda")
 kw = ctx.schedule_key(key, layout=pkg.LAYOUT_PACKED, key_slab=True)
 wit = ctx.encrypt_witness(pt, None, layout=pkg.LAYOUT_PACKED)
 outs = {}
-res = {0: [], 1: []}
+res = {g: [] for g in range(4)}
 for rnd in range(5):
-    for geo in (0, 1):
+    for geo in range(4):
         ctx.set_option("assemble_geometry", geo)
         out = ctx.assemble_advice(k, n_sets, wit, kw, nn, layout=pkg.LAYOUT_PACKED, as_fr=True)
         torch.cuda.synchronize()
@@ -32,8 +33,24 @@ for rnd in range(5):
         torch.cuda.synchronize()
         res[geo].append(e0.elapsed_time(e1) / 10 * 1e3)
         outs[geo] = out
-assert torch.equal(outs[0], outs[1]), "the two geometries disagree"
+assert all(torch.equal(outs[0], outs[g]) for g in range(1, 4)), "the geometries disagree"
 nbytes = outs[0].numel()
-for geo in (0, 1):
+for geo in range(4):
     med = statistics.median(res[geo])
     print("assemble_geometry %d: %8.2f us per %d MiB  -> %6.0f GB/s written" % (geo, med, nbytes >> 20, nbytes / med / 1e3))
+
+# yardstick: expand_fr (same LUT expansion, two-load chain, aligned 4 KiB workgroups) writing the same number of bytes
+cells = torch.randint(0, 256, (nbytes // 32,), dtype=torch.uint8, device="cuda")
+fo = ctx.expand_fr(cells)
+ts = []
+for rnd in range(5):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ctx.expand_fr(cells, out=fo)
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) / 10 * 1e3)
+med = statistics.median(ts)
+print("expand_fr (yardstick):  %8.2f us per %d MiB  -> %6.0f GB/s written" % (med, nbytes >> 20, nbytes / med / 1e3))
