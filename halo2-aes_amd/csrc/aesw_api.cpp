@@ -138,15 +138,6 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), 768), "hipMalloc(tables)");
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_fr_lut), sizeof lut), "hipMalloc(fr_lut)");
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_rk), 256), "hipMalloc(rk)");
-    std::vector<int16_t> pidx(3 * AES_ROWS + 3 * KEY_ROWS);
-    for (int c = 0; c < 3; ++c) {
-        int32_t e[AES_ROWS], kk[KEY_ROWS];
-        aesw_packed_index(c, e);
-        aesw_key_packed_index(c, kk);
-        for (int r = 0; r < AES_ROWS; ++r) pidx[c * AES_ROWS + r] = (int16_t)e[r];
-        for (int r = 0; r < KEY_ROWS; ++r) pidx[3 * AES_ROWS + c * KEY_ROWS + r] = (int16_t)kk[r];
-    }
-    T(hipMalloc(reinterpret_cast<void **>(&ctx->d_pidx), pidx.size() * sizeof(int16_t)), "hipMalloc(pidx)");
     // the flush schedules depend on the layout only: searched once per process (~20 ms each), uploaded per context
     static std::vector<uint32_t> host_ftab[3];
     static std::once_flag ftab_once;
@@ -164,7 +155,6 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
     T(hipEventCreateWithFlags(&ctx->key_ready, hipEventDisableTiming), "hipEventCreate(key_ready)");
     T(hipEventCreateWithFlags(&ctx->key_last_use, hipEventDisableTiming), "hipEventCreate(key_last_use)");
     if (rc == AESW_OK) T(warm_launch_attributes(), "hipFuncSetAttribute(max dynamic LDS)");
-    if (rc == AESW_OK) T(hipMemcpy(ctx->d_pidx, pidx.data(), pidx.size() * sizeof(int16_t), hipMemcpyHostToDevice), "hipMemcpy(pidx)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_fr_lut, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy(fr_lut)");
     if (rc != AESW_OK) {
@@ -189,7 +179,6 @@ void aesw_destroy(aesw_ctx *ctx) {
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
         if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
         if (ctx->d_rk) (void)hipFree(ctx->d_rk);
-        if (ctx->d_pidx) (void)hipFree(ctx->d_pidx);
         for (uint32_t *t : ctx->d_ftab)
             if (t) (void)hipFree(t);
         if (ctx->key_ready) (void)hipEventDestroy(ctx->key_ready);
@@ -540,7 +529,6 @@ int fill_assemble_params(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64_t n_
     *p = AssembleParams{};
     p->x = d_x; p->y = d_y; p->z = d_z;
     if (ks) { p->kw = ks->w; p->kx = ks->kx; p->ky = ks->ky; p->kz = ks->kz; }
-    p->pidx = ctx->d_pidx;
     p->fr_lut = ctx->d_fr_lut;
     p->n_blocks = n_blocks;
     p->k = k;

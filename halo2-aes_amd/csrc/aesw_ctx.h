@@ -14,7 +14,6 @@ struct aesw_ctx {
     uint8_t *d_tables = nullptr;  // 768 B
     uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
     uint8_t *d_rk = nullptr;      // 176 B: round keys of the key given to aesw_schedule_key*
-    int16_t *d_pidx = nullptr;    // dense row -> packed index tables: enc[3][1360], key[3][400]
     uint32_t *d_ftab[3] = {nullptr, nullptr, nullptr};  // flush descriptors per layout (aesw_layout.h "scheduled flush")
     bool have_key = false;
     void *key_stream = nullptr;      // the stream the scheduled key's round keys were written on

@@ -50,7 +50,6 @@ hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t
 struct AssembleParams {
     const uint8_t *x, *y, *z;        // n_blocks slabs
     const uint8_t *kw, *kx, *ky, *kz;  // one key slab (any may be null)
-    const int16_t *pidx;             // enc[3][1360] then key[3][400]: dense row -> packed index (or -1)
     const void *fr_lut;              // 256 x 32 B
     uint8_t *out;
     uint64_t n_blocks;
