@@ -149,6 +149,45 @@ def test_scheduled_key_capture_on_a_foreign_stream_is_refused(pkg, oracle):
     c.close()
 
 
+def test_probed_arena_2p22_blocks_per_block_keys_columns_beyond_4_gib(pkg, oracle):
+    """2^22 blocks with per-block keys into ONE probed arena: 16.7 GB, the x column alone 5.7 GB, so every offset past 2^32
+    and the arena's bookkeeping of several multi-GB candidates are exercised.  8 192 blocks sampled over the whole range
+    (first and last included) equal the oracle in all eight columns; the launch runs at the rate the arena measured."""
+    import torch
+    n = 1 << 22
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip("needs ~60 GB of free HBM")
+    c = pkg.Context(0)
+    w = c.alloc_columns(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
+    info = c.last_arena
+    assert info["bytes"] >= n * 3976 and info["candidates"] >= 1
+    assert w.x.numel() == n * 1360 > 1 << 32
+    g = torch.Generator(device="cuda").manual_seed(0xA35128 + 22)
+    dpt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+    dkeys = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+    got = c.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, want_ct=True, key_slab=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    c.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, want_ct=True, key_slab=True)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    assert us < 1.5 * info["probe_us"], (us, info)  # a launch costs what the probe's emulation of it cost
+    sample = np.unique(np.concatenate([[0, n - 1], np.random.default_rng(22).integers(0, n, 8190)]))
+    ds = torch.from_numpy(sample).cuda()
+    pt, keys = dpt[ds].cpu().numpy(), dkeys[ds].cpu().numpy()
+    e = oracle.encrypt_witness(pt, keys, layout=ol.PACKED, threads=16)
+    k = oracle.key_schedule_witness(keys, layout=ol.PACKED, threads=16)
+    for name, stride in (("x", 1360), ("y", 1056), ("z", 608)):
+        assert np.array_equal(getattr(got, name).view(n, stride)[ds].cpu().numpy().reshape(-1), getattr(e, name)), name
+    assert np.array_equal(got.ct[ds].cpu().numpy(), e.ct)
+    for name, stride in (("w", ol.WORDS_ROWS), ("kx", 400), ("ky", 240), ("kz", 200)):
+        assert np.array_equal(getattr(got.key, name).view(n, stride)[ds].cpu().numpy().reshape(-1), getattr(k, name)), name
+    c.free_columns(w)
+    c.close()
+
+
 def test_assemble_oneshot_geometry_equals_the_striding_kernel_and_synthesize(ctx, pkg, oracle):
     """assemble_geometry 1 (round 3: one-shot workgroups on a (chunk, segment, column) grid, no division in the kernel) and 2 / 3
     (one-shot workgroups on one / two aligned 4 KiB chunks of the output; 3 is the default) write the same Fr columns as the striding kernel, and both equal the restated synthesize() of a K = 12, N = 2 circuit with a
