@@ -147,6 +147,40 @@ def test_fips_kats_are_valid_for_the_reference_table(oracle):
         assert not np.any(kw.kx[key_sbox_rows] == 0xFF)
 
 
+def _openssl_ecb(key: bytes, data: bytes) -> bytes:
+    import subprocess
+    r = subprocess.run(["openssl", "enc", "-aes-128-ecb", "-nopad", "-K", key.hex()], input=data, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, check=True)
+    return r.stdout
+
+
+@pytest.mark.skipif(__import__("shutil").which("openssl") is None, reason="needs the openssl command line tool")
+def test_oracle_against_an_independent_aes(oracle):
+    """A second, unrelated implementation (OpenSSL's AES-128-ECB) over 8 random keys x 2 048 random blocks: the oracle run
+    with the FIPS-197 tables reproduces every ciphertext; run with the reference's tables it reproduces exactly those whose
+    S-box inputs (the x cells of the SubBytes rows and of the key schedule's S-box rows) never reach entry 255, the one
+    entry where src/constant.rs differs from FIPS-197 -- and differs on every other block."""
+    rng = np.random.default_rng(197)
+    fips = ol.Oracle(tables=oracle.fips_tables())
+    sbox_rows = np.concatenate([np.arange(32 + 144 * r, 48 + 144 * r) for r in range(9)] + [np.arange(1328, 1344)])
+    key_sbox_rows = np.concatenate([np.arange(40 * r, 40 * r + 4) for r in range(10)])
+    n, same, differ = 2048, 0, 0
+    for _ in range(8):
+        key = rng.integers(0, 256, 16, dtype=np.uint8)
+        pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+        want = np.frombuffer(_openssl_ecb(key.tobytes(), pt.tobytes()), np.uint8).reshape(n, 16)
+        assert np.array_equal(fips.encrypt_witness(pt, key, layout=ol.PACKED).ct, want)
+        w = oracle.encrypt_witness(pt, key, layout=ol.DENSE)
+        kw = oracle.key_schedule_witness(key, layout=ol.DENSE)
+        key_clean = not np.any(kw.kx[key_sbox_rows] == 0xFF)
+        clean = ~np.any(w.x.reshape(n, 1360)[:, sbox_rows] == 0xFF, axis=1) & key_clean
+        assert np.array_equal(w.ct[clean], want[clean])
+        # a block that looks up S_BOX[255] gets one wrong byte into the state; every later round spreads it
+        assert np.all(np.any(w.ct[~clean] != want[~clean], axis=1)) or not key_clean
+        same, differ = same + int(clean.sum()), differ + int((~clean).sum())
+    assert same > 4000 and differ > 4000  # ~46 % / 54 % of 16 384
+
+
 def test_reference_sbox_changes_ciphertexts(oracle):
     """SURVEY finding 1: about 55 % of random (pt,key) pairs differ from real AES-128."""
     rng = np.random.default_rng(2000)
