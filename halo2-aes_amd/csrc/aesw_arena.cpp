@@ -20,9 +20,6 @@ bool valid_layout(int l) { return aesw_valid_layout(l); }
 
 extern "C" {
 
-// ---- one arena for every output column of a batch, chosen by measurement -----------------
-// (include/aesw.h "Placement probing"; the study behind it: profiles/r03_study/README.md, tools/allocbench.hip)
-
 namespace {
 
 // A virtual range of `total` bytes backed by physical chunks of `chunk` bytes each (the last one shorter).
@@ -102,8 +99,8 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     // Search by measurement.  A UNIT is what one candidate backs: the whole set of columns in one range ("arena_unit" 0), or
     // one column ("arena_unit" 1: greedy, largest column first).  For every unit up to `probe` candidates are built -- a plain
     // hipMalloc, then virtual ranges over physical chunks of 8 / 2 / 32 / 4 MiB, and round again --, the store-pattern
-    // emulation and a linear fill are timed over the units chosen so far PLUS the candidate, the candidate with the best
-    // ratio is kept (the search of a unit stops at the first candidate whose pattern runs as fast as its fill).  Candidates
+    // emulation and a linear fill are timed over the units chosen so far PLUS the candidate, the candidate whose pattern
+    // runs fastest is kept (the search of a unit stops at the first candidate whose pattern runs as fast as its fill).  Candidates
     // that lose are HELD until the whole search is over (otherwise the driver hands the same memory out again), then released.
     using Range = aesw_ctx::ArenaRange;
     const uint32_t strides7[7] = {(uint32_t)sx, (uint32_t)sy, (uint32_t)sz, WORDS_ROWS, aesw_key_column_stride(layout, 0),

@@ -219,15 +219,20 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
  * backs the columns: the same kernel, inputs and virtual layout took 600 us on one allocation and 770 us on the next,
  * stable for the life of an allocation, while a linear fill of the same buffers took 587 us on both.  The property
  * belongs to the combination of columns (256 MiB tiles that all look fast in isolation combine into slow sets) and no
- * virtual-address rule predicts it, so the arena is chosen by measurement, one column at a time, largest first: up to
- * "arena_probe" candidate backings per unit (default 8 for batches of at least 2^16 blocks; 0 = off: one hipMalloc,
- * columns on 2^arena_align_log2-byte boundaries, default 2 MiB) are built with the virtual-memory API from physical
- * chunks of 2 ... 32 MiB; a store-only emulation of the kernel's pattern over the columns placed so far plus the
- * candidate is timed against a linear fill of the same bytes; the first candidate whose pattern runs as fast as its
- * fill is kept, otherwise the one with the best ratio; the rest go back to the driver when the search is over.
- * probe_us / fill_us report the two times for the complete set as finally placed.  Probing writes garbage into the
- * (uninitialised) columns and takes 0.1 - 0.5 s for a 2^20-block set.  With probing every column is its own 2 MiB
- * aligned virtual range; `base` is then only the handle the arena is freed by, `bytes` the sum of the ranges.
+ * virtual-address rule predicts it, so the arena is chosen by measurement.  A UNIT is what one candidate backs: the whole
+ * set of columns in one range, or one column ("arena_unit", below).  Per unit up to "arena_probe" candidate backings
+ * (default 8 for batches of at least 2^16 blocks; 0 = off: one hipMalloc, columns on 2^arena_align_log2-byte boundaries,
+ * default 2 MiB) are built -- a plain hipMalloc, then virtual ranges over physical chunks of 8 / 2 / 32 / 4 MiB
+ * (hipMemCreate / hipMemMap) --; a store-only emulation of the kernel's pattern over the units placed so far plus the
+ * candidate is timed against a linear fill of the same bytes; the first candidate whose pattern runs within 2.5 % of the
+ * fill is kept, otherwise the fastest one; the rest are held until the search is over (or the driver would hand the same
+ * memory out again) and then go back.  Default ("arena_unit" 2): whole-set candidates first, and only when none of them
+ * passes (batches of 2^18 blocks and more) a second search that places the columns one at a time, largest first; the
+ * better of the two is kept.  probe_us / fill_us report the two times for the complete set as finally placed.
+ * Probing writes garbage into the (uninitialised) columns, runs on the device's null stream (it synchronises with the
+ * caller's blocking streams: allocate outside timed or latency-critical sections), never lets the held candidates take
+ * the device's last 16 GB, and takes 0.2 - 1.5 s for a 2^20-block set (up to 5 s on a GPU where no candidate is fast).  Every column
+ * starts on a 2 MiB boundary; with probing `base` is only the handle the arena is freed by and `bytes` the sum of its ranges.
  * Unused members are NULL.  aesw_columns_free releases the arena and clears the struct; cols must come from
  * aesw_columns_alloc on the same context. */
 typedef struct aesw_columns {
@@ -238,7 +243,7 @@ typedef struct aesw_columns {
     uint8_t *z;
     uint8_t *ct;    /* n * 16, or NULL */
     aesw_key_slab key; /* n key slabs, or NULLs */
-    uint32_t candidates; /* column backings probed in all (0: probing off) */
+    uint32_t candidates; /* candidate backings built and timed in all, over every unit (0: probing off) */
     uint32_t chosen;     /* reserved (0) */
     float probe_us;      /* store-pattern emulation over the set as placed, microseconds per pass */
     float fill_us;       /* a linear fill of the same bytes */
