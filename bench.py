@@ -193,6 +193,67 @@ class Runner:
         return wall, ms, self.graph is not None
 
 
+def overlapped_launches(pkg, ctx, torch, n, per_block_keys, branch_counts, steps, arena):
+    """Independent batches issued on b streams of ONE hipGraph (fork, round-robin launches, join), for every b in
+    branch_counts: the ramp and tail of one launch overlap the body of the next.  Shared key passed by pointer (the
+    scheduled-key form can only be captured on the stream its key was scheduled on); own output set per in-flight launch.
+    Returns {b: microseconds per launch = whole graph / steps, median of 5 replays}."""
+    lib = pkg.load_library()
+    g = torch.Generator(device="cpu").manual_seed(SEED + 11)
+    pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g).cuda()
+    keys = torch.randint(0, 256, (n, 16) if per_block_keys else (16,), dtype=torch.uint8, generator=g).cuda()
+    per_set = (3024 + (936 if per_block_keys else 0)) * n
+    # every stream owns its output sets (two streams never write the same bytes at once); as many per stream as keep a byte
+    # from being rewritten while the 256 MiB Infinity Cache may still hold it
+    ring = 1 if per_set >= (640 << 20) else min(8, -(-(640 << 20) // per_set))
+    per_stream = {b: max(1, -(-ring // b)) for b in branch_counts}
+    nsets = max(b * per_stream[b] for b in branch_counts)
+    sets = [ctx.alloc_columns(n, pkg.LAYOUT_PACKED, key_slab=per_block_keys) if arena
+            else ctx.alloc_witness(n, pkg.LAYOUT_PACKED, want_ct=False, key_slab=per_block_keys, n_keys=n) for _ in range(nsets)]
+    ks = [pkg.api.KeySlab(*[t.data_ptr() for t in w.key[:4]]) if per_block_keys else None for w in sets]
+    overlapped_launches.last_sets = nsets
+
+    def launch(i, sp, b=1):
+        j = (i % b) * per_stream[b] + (i // b) % per_stream[b]
+        w, k = sets[j], ks[j]
+        rc = lib.aesw_encrypt_witness_device(ctx._h, pt.data_ptr(), keys.data_ptr(), 1 if per_block_keys else 0, n, pkg.LAYOUT_PACKED,
+                                             w.x.data_ptr(), w.y.data_ptr(), w.z.data_ptr(), None, C.byref(k) if k is not None else None, sp)
+        if rc:
+            raise RuntimeError("aesw_encrypt_witness_device rc=%d %s" % (rc, lib.aesw_last_error(ctx._h).decode()))
+
+    try:
+        out = {}
+        for branches in branch_counts:
+            streams = [torch.cuda.Stream() for _ in range(branches)]
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=cap):
+                cur = torch.cuda.current_stream()
+                for st in streams:
+                    st.wait_stream(cur)
+                for i in range(steps):
+                    launch(i, C.c_void_p(streams[i % branches].cuda_stream), branches)
+                for st in streams:
+                    cur.wait_stream(st)
+            graph.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                graph.replay()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / steps * 1e6)
+            out[branches] = sorted(ts)[2]
+            del graph
+        return out
+    finally:
+        if arena:
+            for w in sets:
+                ctx.free_columns(w)
+
+
 def usable_cpus():
     """CPUs this process can really run on: the affinity mask, cut down by a cgroup CPU quota if there is one
     (a GPU box hands a 1-GPU job a share of its cores; os.cpu_count() still reports all of them)."""
@@ -597,6 +658,21 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # keep the headline even if an extra fails
                 extras[name] = {"error": str(e)}
+        try:  # independent batches on several streams: ramp and tail of a launch overlap its neighbours
+            ov = {"note": "microseconds per launch (graph time / launches) of independent batches issued round-robin on 1, 2 (, 3) streams of "
+                          "one hipGraph; shared key by pointer; the headline above is the 1-stream form, as its roofline entry is "
+                          "defined per kernel"}
+            for name, nn, xpbk, steps, counts in (("c1_packed", 1 << 16, False, 200, (1, 2, 3)), ("c2_packed", 1 << 20, True, 40, (1, 2))):
+                row = {}
+                bpb = BYTES_PBK if xpbk else BYTES_SHARED
+                for br, us in overlapped_launches(pkg, ctx, torch, nn, xpbk, counts, steps, use_arena).items():
+                    row["streams_%d" % br] = {"us_per_launch": us, "blocks_per_s": nn / us * 1e6,
+                                              "achieved_GBps": bpb * nn / us / 1e3, "frac": bpb * nn / us / 1e3 / HBM_PEAK_GBPS}
+                torch.cuda.empty_cache()
+                ov[name] = row
+            extras["overlapped_batches"] = ov
+        except Exception as e:
+            extras["overlapped_batches"] = {"error": str(e)}
         try:  # where the end-to-end time goes: the host's synthesize() assigning the device witness cell by cell
             k, n_sets = 20, 3
             nn = pkg.block_capacity(k, n_sets)

@@ -22,6 +22,11 @@
  * Conventions: plain pointers and sizes, caller-owned buffers, int status
  * (0 = AESW_OK), no exceptions across the boundary, no global mutable state
  * besides the opaque context.  A context is thread-compatible, not thread-safe.
+ * Streams: the *_device entry points are asynchronous on the stream they are given, and independent batches may be
+ * issued on SEVERAL streams of one context (from one thread) -- launches only read the context's tables.  That is how
+ * a stream of small batches should be run: alone, a 2^16-block launch spends 6 of its 35 us ramping up and draining;
+ * round-robin on two or three streams those phases overlap the neighbours' bodies and a launch costs 29 - 30 us, the
+ * time of a linear fill of its bytes (bench.py "overlapped_batches", tests/test_gpu_round3.py).
  * The library needs a gfx950 device: there is NO CPU fallback -- every entry
  * point that computes returns AESW_ERR_NO_DEVICE / AESW_ERR_HIP instead.
  *

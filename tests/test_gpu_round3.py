@@ -188,6 +188,43 @@ def test_probed_arena_2p22_blocks_per_block_keys_columns_beyond_4_gib(pkg, oracl
     c.close()
 
 
+def test_concurrent_launches_on_one_context_are_byte_exact(pkg, oracle):
+    """Independent batches may be issued on several streams of one context (bench.py "overlapped_batches": ramp and tail of a
+    launch then overlap its neighbours).  Twelve launches -- per-block keys, shared key by pointer and the scheduled key, each
+    with its own inputs and outputs -- round-robin on three streams, no synchronisation in between; every output equals the
+    oracle."""
+    import torch
+    c = pkg.Context(0)
+    rng = np.random.default_rng(77)
+    n = (1 << 14) + 3
+    skey = rng.integers(0, 256, 16, dtype=np.uint8)
+    c.schedule_key(torch.from_numpy(skey).cuda(), layout=pkg.LAYOUT_PACKED, key_slab=False)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    jobs = []
+    for i in range(12):
+        mode = i % 3
+        pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+        keys = rng.integers(0, 256, (n, 16), dtype=np.uint8) if mode == 0 else (rng.integers(0, 256, 16, dtype=np.uint8) if mode == 1 else None)
+        jobs.append((mode, pt, keys, torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda() if keys is not None else None))
+    torch.cuda.synchronize()
+    outs = []
+    for i, (mode, pt, keys, dpt, dkeys) in enumerate(jobs):
+        with torch.cuda.stream(streams[i % 3]):
+            outs.append(c.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, want_ct=True, key_slab=mode == 0))
+    torch.cuda.synchronize()
+    for (mode, pt, keys, _, _), got in zip(jobs, outs):
+        e = oracle.encrypt_witness(pt, keys if keys is not None else skey, layout=ol.PACKED)
+        for col in "xyz":
+            assert np.array_equal(getattr(got, col).cpu().numpy(), getattr(e, col)), (mode, col)
+        assert np.array_equal(got.ct.cpu().numpy(), e.ct)
+        if mode == 0:
+            k = oracle.key_schedule_witness(keys, layout=ol.PACKED)
+            for col in ("w", "kx", "ky", "kz"):
+                assert np.array_equal(getattr(got.key, col).cpu().numpy(), getattr(k, col)), col
+    c.close()
+
+
 def test_assemble_oneshot_geometry_equals_the_striding_kernel_and_synthesize(ctx, pkg, oracle):
     """assemble_geometry 1 (round 3: one-shot workgroups on a (chunk, segment, column) grid, no division in the kernel) and 2 / 3
     (one-shot workgroups on one / two aligned 4 KiB chunks of the output; 3 is the default) write the same Fr columns as the striding kernel, and both equal the restated synthesize() of a K = 12, N = 2 circuit with a
