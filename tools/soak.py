@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak: many byte-exact comparisons against the oracle at sizes where timing-dependent faults show
-(store-data hazards, LDS ordering), random layout / key mode / size / launch options per iteration."""
+(store-data hazards, LDS ordering), random layout / key mode / size / launch options per iteration; every third iteration
+the four assemble geometries on a random circuit shape, every fourth three launches in flight on three streams."""
 import os
 import sys
 import time
@@ -67,6 +68,53 @@ for it in range(iters):
             if not np.array_equal(getattr(got.key, c).cpu().numpy(), getattr(kexp, c)):
                 print("MISMATCH key slab", c, "iter", it)
                 sys.exit(1)
+    if it % 3 == 0 and pkg.block_capacity(11, 2) > 0:
+        # round 3: the Fr form of assemble in its four geometries on a random circuit shape (partly filled last set), all equal,
+        # and equal to the restated synthesize() through the byte -> Fr table
+        k, n_sets = int(rng.integers(11, 17)), int(rng.integers(2, 5))
+        cap = pkg.block_capacity(k, n_sets)
+        nb = int(rng.integers(max(1, cap - 3), cap + 1))
+        lay = pkg.LAYOUT_PACKED if rng.integers(0, 2) else pkg.LAYOUT_DENSE
+        akey = torch.from_numpy(keys[1]).cuda()
+        kw = ctx.schedule_key(akey, layout=lay, key_slab=True)
+        wit = ctx.encrypt_witness(dpt[:nb], None, layout=lay)
+        outs = []
+        for geo in range(4):
+            ctx.set_option("assemble_geometry", geo)
+            outs.append(ctx.assemble_advice(k, n_sets, wit, kw, nb, layout=lay, as_fr=True))
+        torch.cuda.synchronize()
+        for geo in range(1, 4):
+            if not torch.equal(outs[0], outs[geo]):
+                print("MISMATCH assemble geometry %d vs 0: iter %d K %d N %d layout %d blocks %d" % (geo, it, k, n_sets, lay, nb))
+                sys.exit(1)
+        if k <= 14:
+            if "fr_lut" not in globals():
+                fr_mod = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+                fr_lut = np.stack([np.frombuffer(((v << 256) % fr_mod).to_bytes(32, "little"), np.uint8) for v in range(256)])
+            a3 = outs[3].cpu().numpy()
+            with orc.circuit(k, n_sets, keys[1], pt[:nb], record_copies=False) as c:
+                for col in range(3 * n_sets + 1):
+                    if not np.array_equal(a3[col], fr_lut[c.advice(col)]):
+                        print("MISMATCH assemble vs synthesize: iter %d K %d N %d layout %d column %d" % (it, k, n_sets, lay, col))
+                        sys.exit(1)
+    if it % 4 == 1:
+        # round 3: three launches with different inputs in flight on three streams of this context
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        m = min(n, 1 << 16)
+        ins = [torch.from_numpy(np.roll(pt[:m], j + 1, axis=0)).cuda() for j in range(3)]
+        dk = torch.from_numpy(keys[2]).cuda()
+        torch.cuda.synchronize()
+        res = []
+        for j in range(3):
+            with torch.cuda.stream(streams[j]):
+                res.append(ctx.encrypt_witness(ins[j], dk, layout=layout, want_ct=True))
+        torch.cuda.synchronize()
+        for j in range(3):
+            e = orc.encrypt_witness(np.roll(pt[:m], j + 1, axis=0), keys[2], layout=layout, threads=threads)
+            for c in "xyz":
+                if not np.array_equal(getattr(res[j], c).cpu().numpy(), getattr(e, c)):
+                    print("MISMATCH concurrent launch %d column %s iter %d" % (j, c, it))
+                    sys.exit(1)
     ctx.close()
     if it % 10 == 9:
         print("iter %d ok (%.0f s)" % (it + 1, time.time() - t0), flush=True)
