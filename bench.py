@@ -543,11 +543,12 @@ def main():
             hpt, pinned_outs = host_bufs   # page-locked input, like the outputs
             hpt[:] = np.random.default_rng(SEED).integers(0, 256, (nn, 16), dtype=np.uint8)
             res = {"blocks": nn, "note": "aesw_encrypt_witness: H2D + kernels + overlapped D2H, packed layout, 2^15-block chunks"}
-            for kind in ("pinned", "pageable"):
+            for kind in ("pinned", "pageable", "pageable_1_copy_thread"):
                 if kind == "pinned":
                     outs = pinned_outs
                 else:
                     outs = [np.empty(nn * pkg.column_stride(pkg.LAYOUT_PACKED, c), np.uint8) for c in range(3)]
+                ctx.set_option("copy_threads", 1 if kind == "pageable_1_copy_thread" else -1)
                 ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_PACKED, out_cols=outs)  # sizes the context's buffers
                 dts = []
                 for _ in range(3):
@@ -556,7 +557,10 @@ def main():
                     dts.append(time.perf_counter() - t0)
                 dt = sorted(dts)[1]  # median of three calls
                 res[kind] = {"blocks_per_s": nn / dt, "GBps_to_host": nn * 3024 / dt / 1e9}
+                if kind == "pageable":
+                    res[kind]["copy_threads"] = ctx.get_option("effective_copy_threads")
                 del outs
+            ctx.set_option("copy_threads", -1)
             vouts = [np.empty(0, np.uint8), pinned_outs[1][:nn * 448], pinned_outs[2][:nn * 608]]
             ctx.encrypt_witness_host(hpt, None, layout=pkg.LAYOUT_VALUES, out_cols=vouts)
             dts = []

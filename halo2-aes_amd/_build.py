@@ -79,7 +79,7 @@ def build_product(force: bool = False) -> Path:
             if not force and _newer(LIB, deps):
                 return LIB  # another process built it while we waited
             tmp = LIB.with_suffix(".so.tmp%d" % os.getpid())
-            _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+            _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-pthread",
                   "-o", str(tmp)] + [str(s) for s in srcs])
             os.replace(tmp, LIB)
         finally:

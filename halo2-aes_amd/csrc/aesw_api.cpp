@@ -2,6 +2,7 @@
 // Host code only (compiled by hipcc for the HIP runtime API).  There is no CPU
 // compute path: without a usable device every computing entry point fails.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/aesw.h"
@@ -355,10 +358,41 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
 #endif
     if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { if (value < 64) return AESW_ERR_INVALID_ARG; ctx->chunk_blocks = value; return AESW_OK; }
+    if (!std::strcmp(name, "copy_threads")) { if (value < -1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->copy_threads = (int)value; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
 }
 
 static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk);
+// Pageable destinations of the host-pointer entry points: a stage arrives in the page-locked bounce buffer by DMA and is
+// moved on from there by the CPU.  One thread moves ~20 GB/s (less into memory it touches for the first time), the link
+// delivers 55: the move is cut into 4 MiB slices handed out to "copy_threads" threads (the caller is one of them).
+struct CopyJob { uint8_t *dst; const uint8_t *src; size_t bytes; };
+static int auto_copy_threads(const aesw_ctx *ctx) {
+    if (ctx->copy_threads >= 0) return ctx->copy_threads < 1 ? 1 : ctx->copy_threads;
+    cpu_set_t set;
+    int usable = 1;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) usable = CPU_COUNT(&set);
+    const int t = usable / 4;  // leave the host its cores: a quarter of what this process may run on, 1 ... 4
+    return t < 1 ? 1 : (t > 4 ? 4 : t);
+}
+static void parallel_copy(const std::vector<CopyJob> &jobs, int threads) {
+    constexpr size_t SLICE = (size_t)4 << 20;
+    std::vector<CopyJob> slices;
+    for (const CopyJob &j : jobs)
+        for (size_t o = 0; o < j.bytes; o += SLICE) slices.push_back(CopyJob{j.dst + o, j.src + o, j.bytes - o < SLICE ? j.bytes - o : SLICE});
+    if ((int)slices.size() < threads) threads = (int)slices.size();
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i = next.fetch_add(1); i < slices.size(); i = next.fetch_add(1)) std::memcpy(slices[i].dst, slices[i].src, slices[i].bytes);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) {
+        try { pool.emplace_back(work); } catch (...) { break; }  // no thread to be had: the caller copies the rest
+    }
+    work();
+    for (std::thread &t : pool) t.join();
+}
+
 static int auto_waves_key(const aesw_ctx *ctx, int layout);
 
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
@@ -383,6 +417,8 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "arena_unit")) { *value = ctx->arena_unit; return AESW_OK; }
     if (!std::strcmp(name, "force_table_path")) { *value = ctx->xt ? 0 : 1; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { *value = ctx->chunk_blocks; return AESW_OK; }
+    if (!std::strcmp(name, "copy_threads")) { *value = ctx->copy_threads; return AESW_OK; }
+    if (!std::strcmp(name, "effective_copy_threads")) { *value = auto_copy_threads(ctx); return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
 }
 
@@ -730,9 +766,10 @@ int aesw_encrypt_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, 
     auto drain = [&](int s) -> int {
         if (!stage_busy[s]) return AESW_OK;
         HIP_TRY(ctx, hipEventSynchronize(copied[s]));
+        std::vector<CopyJob> jobs;
         for (const HostCol &c : cols)
-            if (c.dst && !c.direct)
-                std::memcpy(c.dst + stage_b0[s] * c.stride, ctx->bounce[s] + c.boff, stage_m[s] * c.stride);
+            if (c.dst && !c.direct) jobs.push_back(CopyJob{c.dst + stage_b0[s] * c.stride, ctx->bounce[s] + c.boff, (size_t)(stage_m[s] * c.stride)});
+        if (!jobs.empty()) parallel_copy(jobs, auto_copy_threads(ctx));
         stage_busy[s] = false;
         return AESW_OK;
     };
@@ -1004,7 +1041,7 @@ int aesw_assemble_advice_host(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint64
     auto drain = [&](int s) -> int {  // the device slot (and bounce buffer) of stage s is free again after this
         if (!busy[s]) return AESW_OK;
         HIP_TRY(ctx, hipEventSynchronize(copied[s]));
-        if (!direct) std::memcpy(out + (size_t)held[s] * col_bytes, ctx->bounce[s], col_bytes);
+        if (!direct) parallel_copy({CopyJob{out + (size_t)held[s] * col_bytes, ctx->bounce[s], (size_t)col_bytes}}, auto_copy_threads(ctx));
         busy[s] = false;
         return AESW_OK;
     };

@@ -49,6 +49,7 @@ struct aesw_ctx {
     uint64_t *trace = nullptr;
 #endif
     int64_t chunk_blocks = 1 << 15;  // host-pointer path: blocks per pipeline stage
+    int copy_threads = -1;           // host threads that move a stage from the page-locked bounce buffer into a pageable destination (-1 = auto)
     std::string last_error;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
     uint8_t *bounce[2] = {nullptr, nullptr};  // page-locked staging for pageable destinations

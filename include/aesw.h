@@ -363,7 +363,8 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * "store_mode" (0 plain, 1 nontemporal: the default, 2 write-through sc1), "nt_stores" (0/1), "grid_cap" (max workgroups per launch,
  * 0 = one per block group), "xcd_remap" (which block groups the workgroups of one XCD take: 0 = dispatch order, 1 = one contiguous eighth of
  * the block groups per XCD (default), C >= 2 = the XCDs take turns in chunks of C groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
- * pipeline, default 2^15), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
+ * pipeline, default 2^15), "copy_threads" (host threads that move a stage from the page-locked bounce buffer into a PAGEABLE destination;
+ * -1 = auto: a quarter of the CPUs the process may run on, 1 ... 4; page-locked destinations receive the DMA directly and use none), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB
  * workgroups: the default, 2 one-shot 16 KiB), "assemble_geometry" (Fr form of aesw_assemble_advice_*: 0 striding workgroups,
  * 1 division-free one-shot workgroups on a (chunk, segment, column) grid, 2 / 3 one-shot workgroups writing one / two aligned 4 KiB
@@ -372,7 +373,7 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * backs: 0 = the whole set of columns in one range; 1 = one column, placed greedily, largest first; 2 = whole sets first, then
  * columns if no whole-set candidate ran the pattern as fast as its fill: the default).
  * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
- * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied).
+ * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied), and "effective_copy_threads".
  * Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);

@@ -188,6 +188,33 @@ def test_probed_arena_2p22_blocks_per_block_keys_columns_beyond_4_gib(pkg, oracl
     c.close()
 
 
+def test_pageable_destinations_with_one_and_several_copy_threads(pkg, oracle):
+    """The host-pointer path into ordinary (pageable) arrays moves every stage out of the page-locked bounce buffer with
+    "copy_threads" host threads in 4 MiB slices: 1, 3 and the automatic count give the oracle's bytes for a batch whose stages
+    are several slices long (2^14-block stages: 21 MB of x), ragged at the end, per-block keys + key slabs + ciphertext; the
+    Fr columns of a circuit take the same route column by column."""
+    c = pkg.Context(0)
+    rng = np.random.default_rng(404)
+    n = 3 * (1 << 14) + 1234
+    pt, keys = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    exp = oracle.encrypt_witness(pt, keys, layout=ol.PACKED, threads=16)
+    kexp = oracle.key_schedule_witness(keys, layout=ol.PACKED, threads=16)
+    c.set_option("chunk_blocks", 1 << 14)
+    assert c.get_option("copy_threads") == -1 and 1 <= c.get_option("effective_copy_threads") <= 4
+    for threads in (1, 3, -1):
+        c.set_option("copy_threads", threads)
+        assert c.get_option("copy_threads") == threads
+        got = c.encrypt_witness_host(pt, keys, layout=ol.PACKED, want_ct=True, key_slab=True)
+        for col in "xyz":
+            assert np.array_equal(getattr(got, col), getattr(exp, col)), (threads, col)
+        assert np.array_equal(got.ct, exp.ct)
+        for col in ("w", "kx", "ky", "kz"):
+            assert np.array_equal(getattr(got.key, col), getattr(kexp, col)), (threads, col)
+    with pytest.raises(Exception):
+        c.set_option("copy_threads", 65)
+    c.close()
+
+
 def test_concurrent_launches_on_one_context_are_byte_exact(pkg, oracle):
     """Independent batches may be issued on several streams of one context (bench.py "overlapped_batches": ramp and tail of a
     launch then overlap its neighbours).  Twelve launches -- per-block keys, shared key by pointer and the scheduled key, each
