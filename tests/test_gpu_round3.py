@@ -215,6 +215,32 @@ def test_pageable_destinations_with_one_and_several_copy_threads(pkg, oracle):
     c.close()
 
 
+def test_arena_that_cannot_fit_fails_cleanly_and_leaks_nothing(pkg):
+    """aesw_columns_alloc for more memory than the device has (2^27 blocks with key slabs: 534 GB) returns an error with a
+    message instead of crashing, with and without probing; nothing stays allocated, and the next ordinary arena works."""
+    import torch
+    c = pkg.Context(0)
+    torch.cuda.synchronize()
+    free0, total = torch.cuda.mem_get_info()
+    assert total < 400 << 30
+    # (arena_probe, arena_unit): auto, no probing, whole sets only, and columns one at a time -- there the 182 GB x column fits
+    # and is probed before the next one fails, so the error path has something to give back
+    for probe, unit in ((-1, 2), (0, 2), (2, 0), (1, 1)):
+        c.set_option("arena_probe", probe)
+        c.set_option("arena_unit", unit)
+        with pytest.raises(Exception) as ei:
+            c.alloc_columns(1 << 27, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
+        assert "hip" in str(ei.value).lower() or "memory" in str(ei.value).lower(), str(ei.value)
+    c.set_option("arena_probe", -1)
+    c.set_option("arena_unit", 2)
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 >= free0 - (64 << 20), (free0, free1)
+    w = c.alloc_columns(1 << 16, pkg.LAYOUT_PACKED, key_slab=True)
+    assert w.x.numel() == (1 << 16) * 1360 and c.last_arena["candidates"] >= 1
+    c.free_columns(w)
+    c.close()
+
+
 def test_concurrent_launches_on_one_context_are_byte_exact(pkg, oracle):
     """Independent batches may be issued on several streams of one context (bench.py "overlapped_batches": ramp and tail of a
     launch then overlap its neighbours).  Twelve launches -- per-block keys, shared key by pointer and the scheduled key, each
