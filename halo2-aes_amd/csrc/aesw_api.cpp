@@ -375,19 +375,25 @@ static int auto_copy_threads(const aesw_ctx *ctx) {
     const int t = usable / 4;  // leave the host its cores: a quarter of what this process may run on, 1 ... 4
     return t < 1 ? 1 : (t > 4 ? 4 : t);
 }
-static void parallel_copy(const std::vector<CopyJob> &jobs, int threads) {
+static void parallel_copy(const std::vector<CopyJob> &jobs, int threads) noexcept {
     constexpr size_t SLICE = (size_t)4 << 20;
     std::vector<CopyJob> slices;
-    for (const CopyJob &j : jobs)
-        for (size_t o = 0; o < j.bytes; o += SLICE) slices.push_back(CopyJob{j.dst + o, j.src + o, j.bytes - o < SLICE ? j.bytes - o : SLICE});
+    std::vector<std::thread> pool;
+    try {
+        for (const CopyJob &j : jobs)
+            for (size_t o = 0; o < j.bytes; o += SLICE) slices.push_back(CopyJob{j.dst + o, j.src + o, j.bytes - o < SLICE ? j.bytes - o : SLICE});
+        pool.reserve(threads > 1 ? (size_t)threads - 1 : 0);
+    } catch (...) {  // no memory for the bookkeeping: copy on this thread (nothing has been started yet)
+        for (const CopyJob &j : jobs) std::memcpy(j.dst, j.src, j.bytes);
+        return;
+    }
     if ((int)slices.size() < threads) threads = (int)slices.size();
     std::atomic<size_t> next{0};
-    auto work = [&] {
+    auto work = [&]() noexcept {
         for (size_t i = next.fetch_add(1); i < slices.size(); i = next.fetch_add(1)) std::memcpy(slices[i].dst, slices[i].src, slices[i].bytes);
     };
-    std::vector<std::thread> pool;
     for (int t = 1; t < threads; ++t) {
-        try { pool.emplace_back(work); } catch (...) { break; }  // no thread to be had: the caller copies the rest
+        try { pool.emplace_back(work); } catch (...) { break; }  // no thread to be had: the others and the caller copy the rest
     }
     work();
     for (std::thread &t : pool) t.join();
