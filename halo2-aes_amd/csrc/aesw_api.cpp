@@ -346,7 +346,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "key_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->key_nt = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "fr_geometry")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_geo = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "fr_store_mode")) { if (value < 0 || value > 2) return AESW_ERR_INVALID_ARG; ctx->fr_nt = (int)value; return AESW_OK; }
-    if (!std::strcmp(name, "assemble_geometry")) { if (value < 0 || value > 3) return AESW_ERR_INVALID_ARG; ctx->asm_geo = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "assemble_geometry")) { if (value < 0 || value > 4) return AESW_ERR_INVALID_ARG; ctx->asm_geo = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "grid_cap")) { if (value < 0 || value > 0x7fffffff) return AESW_ERR_INVALID_ARG; ctx->grid_cap = value; return AESW_OK; }
     if (!std::strcmp(name, "xcd_remap")) { if (value < 0 || value > (1 << 24)) return AESW_ERR_INVALID_ARG; ctx->xcd_remap = (uint32_t)value; return AESW_OK; }
     if (!std::strcmp(name, "lds_pad")) { if (value < 0 || value > 120 * 1024) return AESW_ERR_INVALID_ARG; ctx->lds_pad = value; return AESW_OK; }

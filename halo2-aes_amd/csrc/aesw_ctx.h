@@ -29,8 +29,8 @@ struct aesw_ctx {
     int key_nt = 1;  // store flavour of key_kernel (one contiguous flush per column at the end): nontemporal 4-9 % ahead of sc1 (tools/keysweep.py)
     int fr_geo = 1;  // geometry of expand_fr: 1 = one-shot 4 KiB workgroups, LUT gathered from global memory: 7.3 TB/s with nontemporal stores
                      // against 5.2 for 0 = striding workgroups + LDS LUT and 5.9 for 2 = one-shot 16 KiB + LDS LUT (tools/frsweep.py)
-    int asm_geo = 3;  // geometry of the Fr form of assemble: 0 striding workgroups, 1 one-shot (chunk, segment, column) grid, 2 / 3 one-shot workgroups
-                      // on 1 / 2 aligned 4 KiB chunks of the output (3 = default: 6.3 TB/s for K = 20, N = 5 against 5.2 striding)
+    int asm_geo = 4;  // geometry of the Fr form of assemble: 0 striding workgroups, 1 one-shot (chunk, segment, column) grid, 2 / 3 / 4 one-shot workgroups
+                      // on aligned output chunks: 256 threads x 1 piece, 256 x 2, 128 x 2 (4 = default: 6.9 TB/s for K = 20, N = 5 against 5.3 striding)
                       // workgroups on a (chunk, segment, column) grid (round 3: byte-exact, 5.2 TB/s -- a piece is a chain of three dependent loads
                       // (index table, slab byte, LUT) and a one-shot workgroup has nothing else in flight: latency x residency bounds it, not divisions)
     int fr_nt = 1;  // store flavour of the Fr-expanding kernels: nontemporal measured 19 % ahead of plain and sc1 there (tools/frsweep.py)

@@ -746,15 +746,22 @@ __global__ void __launch_bounds__(256) assemble_fr_oneshot_kernel(const Assemble
     gstore<NT>(out, lut[v * 2 + (piece & 1)]);
 }
 
-// Geometry 2 / 3 (the default): the same one-shot workgroups cut on the OUTPUT instead -- a workgroup writes PIECES aligned
-// 4 KiB chunks (128 rows each) of one column, expand_fr's GEO 1 -- at the price of one 32-bit division by AES_ROWS per piece
-// (a multiply-high; K <= 30 is checked on the host).  The slab index comes from packed_index_enc/_key instead of the
-// table, everything that depends on the column only is scalar, and with PIECES = 2 a thread has two independent
-// byte -> LUT -> store chains in flight.  Measured (tools/asm_geo.py, N = 5; TB/s written, striding / geometry 1 / 2 / 3 /
-// expand_fr over as many bytes): K = 17: 4.6 / 4.3 / 5.1 / 5.6 / 5.7; K = 20: 5.2 / 5.1 / 6.1 / 6.3 / 7.0;
-// K = 22: 4.2 / 5.4 / 6.2 / 6.7 / 7.1.  Four chunks per workgroup are slower again (5.8).
-template <int NT, int PIECES>
-__global__ void __launch_bounds__(256) assemble_fr_aligned_kernel(const AssembleParams a) {
+// Geometry 2 / 3 / 4 (4 = the default): the same one-shot workgroups cut on the OUTPUT instead -- a workgroup of THREADS
+// threads writes PIECES x THREADS x 16 B of one column, aligned, as expand_fr's GEO 1 does -- at the price of one 32-bit
+// division by AES_ROWS per piece (a multiply-high; K <= 30 is checked on the host).  The slab index comes from
+// packed_index_enc/_key instead of the table, everything that depends on the column only is scalar, and with PIECES = 2 a
+// thread has two independent byte -> LUT -> store chains in flight.  Two things decide the rate: a workgroup should write
+// 4 KiB (8 KiB costs ~8 %, as in expand_fr), and the ~100 VALU instructions of index arithmetic in front of the byte load
+// should overlap another chain (another ~8 %).  Geometry 2 = 256 threads x 1 piece (4 KiB, one chain), 3 = 256 x 2 (8 KiB,
+// two chains), 4 = 128 x 2 (4 KiB, two chains).  Measured (tools/asm_geo.py, N = 5, packed slabs; TB/s written, striding /
+// geometry 1 / 2 / 3 / 4 / expand_fr over as many bytes): K = 20: 5.3 / 5.0 / 6.2 / 6.1 - 6.3 / 6.9 / 6.9;
+// K = 22: 4.1 / 5.5 / 6.3 / 6.6 / 7.1 / 7.2.  (64 threads x 4 pieces: 6.2; 256 x 4: 5.8.)
+template <int NT, int PIECES, int THREADS>
+__global__ void __launch_bounds__(THREADS) assemble_fr_aligned_kernel(const AssembleParams a) {
+    // every kernel argument in SGPRs before anything else: left alone the compiler loads them where they are first used,
+    // behind branches, and a one-shot workgroup then waits for four scalar loads one after the other (worth 3 % in geometry 2)
+    asm volatile("" ::"s"(a.x), "s"(a.y), "s"(a.z), "s"(a.kw), "s"(a.kx), "s"(a.ky), "s"(a.kz), "s"(a.fr_lut), "s"(a.out), "s"(a.n_blocks),
+                 "s"(a.k), "s"(a.n_sets), "s"(a.col_first), "s"(a.sx), "s"(a.sy), "s"(a.sz), "s"(a.packed), "s"(a.cap0), "s"(a.capn));
     const uint32_t col = a.col_first + blockIdx.y;
     const uint32_t n_adv = 3 * a.n_sets;
     const bool words = col == n_adv;
@@ -769,7 +776,7 @@ __global__ void __launch_bounds__(256) assemble_fr_aligned_kernel(const Assemble
     uint32_t row[PIECES], v[PIECES];
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
-        row[j] = ((blockIdx.x * PIECES + j) * 256 + threadIdx.x) >> 1;
+        row[j] = ((blockIdx.x * PIECES + j) * THREADS + threadIdx.x) >> 1;
         v[j] = 0;
         if (words) {
             if (row[j] < WORDS_ROWS && a.kw) v[j] = a.kw[row[j]];
@@ -1046,9 +1053,11 @@ hipError_t launch_table(const uint8_t *tables, uint8_t *t0, uint8_t *t1, uint8_t
 }
 
 template <int NT>
-static void launch_assemble_aligned(int lg, dim3 grid, hipStream_t s, const AssembleParams &p) {
-    if (lg == 0) hipLaunchKernelGGL((assemble_fr_aligned_kernel<NT, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((assemble_fr_aligned_kernel<NT, 2>), grid, dim3(256), 0, s, p);
+static void launch_assemble_aligned(int geo, uint32_t k, uint32_t cols, hipStream_t s, const AssembleParams &p) {
+    // 2^k rows x 2 pieces / (PIECES x THREADS) workgroups per column
+    if (geo == 2) hipLaunchKernelGGL((assemble_fr_aligned_kernel<NT, 1, 256>), dim3(1u << (k - 7), cols), dim3(256), 0, s, p);
+    else if (geo == 3) hipLaunchKernelGGL((assemble_fr_aligned_kernel<NT, 2, 256>), dim3(1u << (k - 8), cols), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((assemble_fr_aligned_kernel<NT, 2, 128>), dim3(1u << (k - 7), cols), dim3(128), 0, s, p);
 }
 
 hipError_t launch_assemble(const AssembleParams &p0, bool as_fr, int nt, hipStream_t s) {
@@ -1069,13 +1078,9 @@ hipError_t launch_assemble(const AssembleParams &p0, bool as_fr, int nt, hipStre
         return hipGetLastError();
     }
     if (as_fr && p.geometry >= 2 && p.col_count > 0 && p.k >= 8 && p.k <= 30 && p.col_count <= 65535) {
-        // a workgroup writes 1 or 2 aligned 4 KiB chunks (geometry 2, 3): 2^k rows x 2 pieces / (256 x chunks) workgroups;
-        // smaller or larger K fall through to the striding kernel
-        const int lg = p.geometry - 2;
-        const dim3 grid(1u << (p.k - 7 - lg), p.col_count);
-        if (nt == 2) launch_assemble_aligned<2>(lg, grid, s, p);
-        else if (nt == 1) launch_assemble_aligned<1>(lg, grid, s, p);
-        else launch_assemble_aligned<0>(lg, grid, s, p);
+        if (nt == 2) launch_assemble_aligned<2>(p.geometry, p.k, p.col_count, s, p);
+        else if (nt == 1) launch_assemble_aligned<1>(p.geometry, p.k, p.col_count, s, p);
+        else launch_assemble_aligned<0>(p.geometry, p.k, p.col_count, s, p);
         return hipGetLastError();
     }
     const uint64_t cells = (uint64_t)p.col_count << p.k;

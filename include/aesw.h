@@ -367,8 +367,9 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * -1 = auto: a quarter of the CPUs the process may run on, 1 ... 4; page-locked destinations receive the DMA directly and use none), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB
  * workgroups: the default, 2 one-shot 16 KiB), "assemble_geometry" (Fr form of aesw_assemble_advice_*: 0 striding workgroups,
- * 1 division-free one-shot workgroups on a (chunk, segment, column) grid, 2 / 3 one-shot workgroups writing one / two aligned 4 KiB
- * chunks of a column: 3 is the default; K < 8 or K > 30 always take the striding kernel), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto), "arena_probe" (candidate backings
+ * 1 division-free one-shot workgroups on a (chunk, segment, column) grid, 2 / 3 / 4 one-shot workgroups on aligned chunks of a
+ * column: 256 threads x 1 piece (4 KiB), 256 x 2 (8 KiB), 128 x 2 (4 KiB): 4 is the default; K < 8 or K > 30 always take the
+ * striding kernel), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto), "arena_probe" (candidate backings
  * aesw_columns_alloc measures per unit, -1 = auto: 8 for batches of at least 2^16 blocks, 0 = none: one hipMalloc), "arena_unit" (what a candidate
  * backs: 0 = the whole set of columns in one range; 1 = one column, placed greedily, largest first; 2 = whole sets first, then
  * columns if no whole-set candidate ran the pattern as fast as its fill: the default).

@@ -279,8 +279,8 @@ def test_concurrent_launches_on_one_context_are_byte_exact(pkg, oracle):
 
 
 def test_assemble_oneshot_geometry_equals_the_striding_kernel_and_synthesize(ctx, pkg, oracle):
-    """assemble_geometry 1 (round 3: one-shot workgroups on a (chunk, segment, column) grid, no division in the kernel) and 2 / 3
-    (one-shot workgroups on one / two aligned 4 KiB chunks of the output; 3 is the default) write the same Fr columns as the striding kernel, and both equal the restated synthesize() of a K = 12, N = 2 circuit with a
+    """assemble_geometry 1 (round 3: one-shot workgroups on a (chunk, segment, column) grid, no division in the kernel) and 2 / 3 / 4
+    (one-shot workgroups on aligned chunks of the output; 4 is the default) write the same Fr columns as the striding kernel, and both equal the restated synthesize() of a K = 12, N = 2 circuit with a
     partly filled last set, never-assigned rows and the words column included."""
     import torch
     k, n_sets = 12, 2
@@ -291,10 +291,10 @@ def test_assemble_oneshot_geometry_equals_the_striding_kernel_and_synthesize(ctx
     kw = ctx.schedule_key(torch.from_numpy(key).cuda(), layout=pkg.LAYOUT_PACKED, key_slab=True)
     wit = ctx.encrypt_witness(torch.from_numpy(pts).cuda(), None, layout=pkg.LAYOUT_PACKED)
     outs = []
-    for geo in range(4):
+    for geo in range(5):
         ctx.set_option("assemble_geometry", geo)
         outs.append(ctx.assemble_advice(k, n_sets, wit, kw, n, layout=pkg.LAYOUT_PACKED, as_fr=True).cpu().numpy())
-    ctx.set_option("assemble_geometry", 3)
+    ctx.set_option("assemble_geometry", 4)
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
     fr_mod = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
     lut = np.stack([np.frombuffer(((v << 256) % fr_mod).to_bytes(32, "little"), np.uint8) for v in range(256)])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak: many byte-exact comparisons against the oracle at sizes where timing-dependent faults show
 (store-data hazards, LDS ordering), random layout / key mode / size / launch options per iteration; every third iteration
-the four assemble geometries on a random circuit shape, every fourth three launches in flight on three streams."""
+the five assemble geometries on a random circuit shape, every fourth three launches in flight on three streams."""
 import os
 import sys
 import time
@@ -79,11 +79,11 @@ for it in range(iters):
         kw = ctx.schedule_key(akey, layout=lay, key_slab=True)
         wit = ctx.encrypt_witness(dpt[:nb], None, layout=lay)
         outs = []
-        for geo in range(4):
+        for geo in range(5):
             ctx.set_option("assemble_geometry", geo)
             outs.append(ctx.assemble_advice(k, n_sets, wit, kw, nb, layout=lay, as_fr=True))
         torch.cuda.synchronize()
-        for geo in range(1, 4):
+        for geo in range(1, 5):
             if not torch.equal(outs[0], outs[geo]):
                 print("MISMATCH assemble geometry %d vs 0: iter %d K %d N %d layout %d blocks %d" % (geo, it, k, n_sets, lay, nb))
                 sys.exit(1)
@@ -91,7 +91,7 @@ for it in range(iters):
             if "fr_lut" not in globals():
                 fr_mod = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
                 fr_lut = np.stack([np.frombuffer(((v << 256) % fr_mod).to_bytes(32, "little"), np.uint8) for v in range(256)])
-            a3 = outs[3].cpu().numpy()
+            a3 = outs[4].cpu().numpy()
             with orc.circuit(k, n_sets, keys[1], pt[:nb], record_copies=False) as c:
                 for col in range(3 * n_sets + 1):
                     if not np.array_equal(a3[col], fr_lut[c.advice(col)]):
