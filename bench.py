@@ -194,10 +194,11 @@ class Runner:
 
 
 def overlapped_launches(pkg, ctx, torch, n, per_block_keys, branch_counts, steps, arena):
-    """Independent batches issued on b streams of ONE hipGraph (fork, round-robin launches, join), for every b in
-    branch_counts: the ramp and tail of one launch overlap the body of the next.  Shared key passed by pointer (the
-    scheduled-key form can only be captured on the stream its key was scheduled on); own output set per in-flight launch.
-    Returns {b: microseconds per launch = whole graph / steps, median of 5 replays}."""
+    """Independent batches through aesw_encrypt_witness_batches_device with "batch_streams" = b for every b in branch_counts:
+    the `steps` batches of one call are dealt round-robin onto b internal streams (fork behind the caller's stream, join back
+    into it), so the ramp and tail of one launch overlap the body of the next; the call is captured into one hipGraph.
+    Shared key passed by pointer (the scheduled-key form can only be captured on the stream its key was scheduled on); every
+    stream writes its own output sets.  Returns {b: microseconds per batch = graph time / steps, median of 5 replays}."""
     lib = pkg.load_library()
     g = torch.Generator(device="cpu").manual_seed(SEED + 11)
     pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g).cuda()
@@ -212,30 +213,29 @@ def overlapped_launches(pkg, ctx, torch, n, per_block_keys, branch_counts, steps
             else ctx.alloc_witness(n, pkg.LAYOUT_PACKED, want_ct=False, key_slab=per_block_keys, n_keys=n) for _ in range(nsets)]
     ks = [pkg.api.KeySlab(*[t.data_ptr() for t in w.key[:4]]) if per_block_keys else None for w in sets]
     overlapped_launches.last_sets = nsets
-
-    def launch(i, sp, b=1):
-        j = (i % b) * per_stream[b] + (i // b) % per_stream[b]
-        w, k = sets[j], ks[j]
-        rc = lib.aesw_encrypt_witness_device(ctx._h, pt.data_ptr(), keys.data_ptr(), 1 if per_block_keys else 0, n, pkg.LAYOUT_PACKED,
-                                             w.x.data_ptr(), w.y.data_ptr(), w.z.data_ptr(), None, C.byref(k) if k is not None else None, sp)
-        if rc:
-            raise RuntimeError("aesw_encrypt_witness_device rc=%d %s" % (rc, lib.aesw_last_error(ctx._h).decode()))
-
     try:
         out = {}
-        for branches in branch_counts:
-            streams = [torch.cuda.Stream() for _ in range(branches)]
+        for b in branch_counts:
+            ctx.set_option("batch_streams", b)
+            arr = (pkg.api.Batch * steps)()
+            for i in range(steps):  # batch i runs on internal stream i % b: give it one of that stream's sets
+                j = (i % b) * per_stream[b] + (i // b) % per_stream[b]
+                w = sets[j]
+                arr[i] = pkg.api.Batch(pt.data_ptr(), keys.data_ptr(), n, w.x.data_ptr(), w.y.data_ptr(), w.z.data_ptr(), None,
+                                       C.pointer(ks[j]) if ks[j] is not None else None)
+
+            def call(sp):
+                rc = lib.aesw_encrypt_witness_batches_device(ctx._h, arr, steps, 1 if per_block_keys else 0, pkg.LAYOUT_PACKED, sp)
+                if rc:
+                    raise RuntimeError("aesw_encrypt_witness_batches_device rc=%d %s" % (rc, lib.aesw_last_error(ctx._h).decode()))
+
+            call(C.c_void_p(torch.cuda.current_stream().cuda_stream))  # untimed: creates the internal streams outside the capture
+            torch.cuda.synchronize()
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=cap):
-                cur = torch.cuda.current_stream()
-                for st in streams:
-                    st.wait_stream(cur)
-                for i in range(steps):
-                    launch(i, C.c_void_p(streams[i % branches].cuda_stream), branches)
-                for st in streams:
-                    cur.wait_stream(st)
+                call(C.c_void_p(torch.cuda.current_stream().cuda_stream))
             graph.replay()
             torch.cuda.synchronize()
             ts = []
@@ -245,10 +245,11 @@ def overlapped_launches(pkg, ctx, torch, n, per_block_keys, branch_counts, steps
                 graph.replay()
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) / steps * 1e6)
-            out[branches] = sorted(ts)[2]
+            out[b] = sorted(ts)[2]
             del graph
         return out
     finally:
+        ctx.set_option("batch_streams", 3)
         if arena:
             for w in sets:
                 ctx.free_columns(w)
@@ -663,9 +664,9 @@ def main():
             except Exception as e:  # keep the headline even if an extra fails
                 extras[name] = {"error": str(e)}
         try:  # independent batches on several streams: ramp and tail of a launch overlap its neighbours
-            ov = {"note": "microseconds per launch (graph time / launches) of independent batches issued round-robin on 1, 2 (, 3) streams of "
-                          "one hipGraph; shared key by pointer; the headline above is the 1-stream form, as its roofline entry is "
-                          "defined per kernel"}
+            ov = {"note": "microseconds per batch (graph time / batches) of independent batches through aesw_encrypt_witness_batches_device "
+                          "with batch_streams = 1, 2 (, 3), captured into one hipGraph; shared key by pointer; the headline above is "
+                          "the 1-stream form, as its roofline entry is defined per kernel"}
             for name, nn, xpbk, steps, counts in (("c1_packed", 1 << 16, False, 200, (1, 2, 3)), ("c2_packed", 1 << 20, True, 40, (1, 2))):
                 row = {}
                 bpb = BYTES_PBK if xpbk else BYTES_SHARED

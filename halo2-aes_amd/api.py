@@ -54,6 +54,12 @@ class Columns(C.Structure):
                 ("probe_us", C.c_float), ("fill_us", C.c_float)]
 
 
+class Batch(C.Structure):
+    """aesw_batch: one batch of aesw_encrypt_witness_batches_device."""
+    _fields_ = [("d_pt", C.c_void_p), ("d_keys", C.c_void_p), ("n", C.c_uint64), ("d_x", C.c_void_p), ("d_y", C.c_void_p),
+                ("d_z", C.c_void_p), ("d_ct", C.c_void_p), ("d_key_slab", C.POINTER(KeySlab))]
+
+
 class _DevView:
     """A raw device range as a __cuda_array_interface__ object, so torch can wrap it without owning it."""
 
@@ -85,6 +91,7 @@ SYMBOLS = {
     "aesw_schedule_key_device": (_I, [_P, _P, _I, C.POINTER(KeySlab), _P]),
     "aesw_schedule_key": (_I, [_P, _P, _I, C.POINTER(KeySlab)]),
     "aesw_encrypt_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P]),
+    "aesw_encrypt_witness_batches_device": (_I, [_P, C.POINTER(Batch), _U32, _I, _I, _P]),
     "aesw_key_schedule_witness_device": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P, _P]),
     "aesw_lookup_table_device": (_I, [_P, _P, _P, _P, _P, _P]),
     "aesw_expand_fr_device": (_I, [_P, _P, _U64, _P, _P]),
@@ -522,6 +529,38 @@ class Context:
             C.byref(ks) if ks is not None else None, self._stream())
         self._check(rc, "aesw_encrypt_witness_device")
         return out
+
+    def encrypt_witness_batches(self, batches, per_block_keys: bool, layout: int = K.LAYOUT_PACKED):
+        """aesw_encrypt_witness_batches_device: `batches` is a list of (pt, keys, out) with pt uint8[n,16], keys None /
+        uint8[16] / uint8[n,16] (all batches in the same key mode) and out a Witness whose columns hold n blocks (its .ct and
+        .key are written when present).  The batches are dealt round-robin onto the context's internal streams behind torch's
+        current stream and joined back into it: ramp and tail of one launch overlap its neighbours."""
+        arr = (Batch * len(batches))()
+        keep = []
+        for i, (pt, keys, out) in enumerate(batches):
+            pt = self._u8(pt, "pt")
+            n = pt.shape[0]
+            if pt.dim() != 2 or pt.shape[1] != 16:
+                raise ValueError("pt must be [n,16]")
+            if keys is not None:
+                keys = self._u8(keys, "keys")
+                if keys.numel() != (n * 16 if per_block_keys else 16):
+                    raise ValueError("keys must hold 16 bytes, or n*16 with per_block_keys")
+            elif per_block_keys:
+                raise ValueError("per_block_keys needs keys")
+            for c, name in enumerate("xyz"):
+                if out[c].numel() < n * column_stride(layout, c):
+                    raise ValueError("column %s of batch %d too small" % (name, i))
+            ks = None
+            if out.key is not None:
+                ks = KeySlab(*[t.data_ptr() if t is not None else None for t in out.key[:4]])
+                keep.append(ks)
+            arr[i] = Batch(pt.data_ptr(), keys.data_ptr() if keys is not None else None, n,
+                           out.x.data_ptr() if out.x.numel() else None, out.y.data_ptr(), out.z.data_ptr(),
+                           out.ct.data_ptr() if out.ct is not None else None, C.pointer(ks) if ks is not None else None)
+            keep.append((pt, keys))
+        rc = self._lib.aesw_encrypt_witness_batches_device(self._h, arr, len(batches), 1 if per_block_keys else 0, layout, self._stream())
+        self._check(rc, "aesw_encrypt_witness_batches_device")
 
     def key_schedule_witness(self, keys, layout: int = K.LAYOUT_PACKED, want_rk: bool = True, out: KeyWitness | None = None) -> KeyWitness:
         """Aes128KeyScheduleConfig::schedule_keys witness for n keys (src/key_schedule.rs:80-224); into `out`

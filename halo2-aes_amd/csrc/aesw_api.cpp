@@ -174,6 +174,11 @@ void aesw_destroy(aesw_ctx *ctx) {
         DeviceGuard g(ctx->device);
         if (ctx->s_compute) (void)hipStreamDestroy(ctx->s_compute);
         if (ctx->s_copy) (void)hipStreamDestroy(ctx->s_copy);
+        for (int j = 0; j < 8; ++j) {
+            if (ctx->s_batch[j]) (void)hipStreamDestroy(ctx->s_batch[j]);
+            if (ctx->ev_join[j]) (void)hipEventDestroy(ctx->ev_join[j]);
+        }
+        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         for (int i = 0; i < 2; ++i)
             if (ctx->bounce[i]) (void)hipHostFree(ctx->bounce[i]);
         if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -358,6 +363,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
 #endif
     if (!std::strcmp(name, "force_table_path")) { if (value) ctx->xt = false; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { if (value < 64) return AESW_ERR_INVALID_ARG; ctx->chunk_blocks = value; return AESW_OK; }
+    if (!std::strcmp(name, "batch_streams")) { if (value < 1 || value > 8) return AESW_ERR_INVALID_ARG; ctx->batch_streams = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "copy_threads")) { if (value < -1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->copy_threads = (int)value; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
 }
@@ -423,6 +429,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "arena_unit")) { *value = ctx->arena_unit; return AESW_OK; }
     if (!std::strcmp(name, "force_table_path")) { *value = ctx->xt ? 0 : 1; return AESW_OK; }
     if (!std::strcmp(name, "chunk_blocks")) { *value = ctx->chunk_blocks; return AESW_OK; }
+    if (!std::strcmp(name, "batch_streams")) { *value = ctx->batch_streams; return AESW_OK; }
     if (!std::strcmp(name, "copy_threads")) { *value = ctx->copy_threads; return AESW_OK; }
     if (!std::strcmp(name, "effective_copy_threads")) { *value = auto_copy_threads(ctx); return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
@@ -535,6 +542,45 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
         }
     }
     return AESW_OK;
+}
+
+int aesw_encrypt_witness_batches_device(aesw_ctx *ctx, const aesw_batch *batches, uint32_t count, int per_block_keys, int layout,
+                                        void *stream) {
+    if (!ctx || !valid_layout(layout) || (count && !batches)) return AESW_ERR_INVALID_ARG;
+    if (count == 0) return AESW_OK;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    const uint32_t ns = (uint32_t)ctx->batch_streams < count ? (uint32_t)ctx->batch_streams : count;
+    if (ns <= 1) {  // nothing to overlap: plain launches on the caller's stream
+        for (uint32_t i = 0; i < count; ++i) {
+            const aesw_batch &b = batches[i];
+            const int rc = aesw_encrypt_witness_device(ctx, b.d_pt, b.d_keys, per_block_keys, b.n, layout, b.d_x, b.d_y, b.d_z, b.d_ct, b.d_key_slab, stream);
+            if (rc != AESW_OK) return rc;
+        }
+        return AESW_OK;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (uint32_t j = 0; j < ns; ++j) {
+        if (!ctx->s_batch[j]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_batch[j], hipStreamNonBlocking));
+        if (!ctx->ev_join[j]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming));
+    }
+    // fork: the internal streams start behind what the caller's stream holds
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
+    for (uint32_t j = 0; j < ns; ++j) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_batch[j], ctx->ev_fork, 0));
+    int rc = AESW_OK;
+    for (uint32_t i = 0; i < count && rc == AESW_OK; ++i) {
+        const aesw_batch &b = batches[i];
+        rc = aesw_encrypt_witness_device(ctx, b.d_pt, b.d_keys, per_block_keys, b.n, layout, b.d_x, b.d_y, b.d_z, b.d_ct, b.d_key_slab,
+                                         ctx->s_batch[i % ns]);
+    }
+    // join, also after a failed launch: what was issued must be ordered before whatever the caller does next on `stream`
+    for (uint32_t j = 0; j < ns; ++j) {
+        const hipError_t e1 = hipEventRecord(ctx->ev_join[j], ctx->s_batch[j]);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, ctx->ev_join[j], 0) : e1;
+        if (e2 != hipSuccess && rc == AESW_OK) rc = fail_hip(ctx, e2, "join of the batch streams");
+    }
+    return rc;
 }
 
 int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint64_t n, int layout, uint8_t *d_w,

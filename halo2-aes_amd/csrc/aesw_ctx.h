@@ -52,6 +52,9 @@ struct aesw_ctx {
     int copy_threads = -1;           // host threads that move a stage from the page-locked bounce buffer into a pageable destination (-1 = auto)
     std::string last_error;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
+    int batch_streams = 3;  // aesw_encrypt_witness_batches_device: internal streams the batches are dealt onto
+    hipStream_t s_batch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint8_t *bounce[2] = {nullptr, nullptr};  // page-locked staging for pageable destinations
     size_t bounce_bytes = 0;
     uint8_t *scratch = nullptr;  // device buffers of the host-pointer path (grow-only)

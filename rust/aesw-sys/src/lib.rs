@@ -105,6 +105,19 @@ pub struct aesw_columns {
     pub fill_us: f32,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct aesw_batch {
+    pub d_pt: *const u8,
+    pub d_keys: *const u8,
+    pub n: u64,
+    pub d_x: *mut u8,
+    pub d_y: *mut u8,
+    pub d_z: *mut u8,
+    pub d_ct: *mut u8,
+    pub d_key_slab: *const aesw_key_slab,
+}
+
 pub type aesw_chunk_fn = unsafe extern "C" fn(
     user: *mut c_void,
     first_block: u64,
@@ -218,6 +231,14 @@ extern "C" {
         d_key_slab: *const aesw_key_slab,
         as_fr: c_int,
         d_out: *mut u8,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn aesw_encrypt_witness_batches_device(
+        ctx: *mut aesw_ctx,
+        batches: *const aesw_batch,
+        count: u32,
+        per_block_keys: c_int,
+        layout: c_int,
         stream: *mut c_void,
     ) -> c_int;
     pub fn aesw_columns_alloc(

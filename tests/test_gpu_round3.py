@@ -241,6 +241,83 @@ def test_arena_that_cannot_fit_fails_cleanly_and_leaks_nothing(pkg):
     c.close()
 
 
+@pytest.mark.parametrize("streams", [1, 3, 8])
+def test_batches_entry_point_is_byte_exact_in_every_key_mode(pkg, oracle, streams):
+    """aesw_encrypt_witness_batches_device: seven batches of different sizes dealt onto 1 / 3 / 8 internal streams, in each key
+    mode (scheduled key, one key by pointer, per-block keys with key slabs and ciphertext); every batch equals the oracle, and
+    work queued on the caller's stream before and after the call is ordered around it (fork / join)."""
+    import torch
+    c = pkg.Context(0)
+    c.set_option("batch_streams", streams)
+    assert c.get_option("batch_streams") == streams
+    rng = np.random.default_rng(500 + streams)
+    sizes = [1, 17, 4096, (1 << 14) + 5, 300, 1 << 13, 63]
+    skey = rng.integers(0, 256, 16, dtype=np.uint8)
+    for mode in ("scheduled", "shared", "per_block"):
+        pbk = mode == "per_block"
+        if mode == "scheduled":
+            c.schedule_key(torch.from_numpy(skey).cuda(), layout=pkg.LAYOUT_PACKED, key_slab=False)
+        host, batches = [], []
+        for n in sizes:
+            pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+            keys = rng.integers(0, 256, (n, 16), dtype=np.uint8) if pbk else (rng.integers(0, 256, 16, dtype=np.uint8) if mode == "shared" else None)
+            out = c.alloc_witness(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=pbk, n_keys=n)
+            for t in (out.x, out.y, out.z, out.ct):
+                t.fill_(0x5A)  # queued on the caller's stream BEFORE the call: the batches must come after it
+            host.append((pt, keys))
+            batches.append((torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda() if keys is not None else None, out))
+        c.encrypt_witness_batches(batches, pbk, layout=pkg.LAYOUT_PACKED)
+        copies = [b[2].x.clone() for b in batches]  # queued AFTER the call on the caller's stream: must see the results
+        torch.cuda.synchronize()
+        for (pt, keys), (_, _, out), cp in zip(host, batches, copies):
+            e = oracle.encrypt_witness(pt, keys if keys is not None else skey, layout=ol.PACKED)
+            for col in "xyz":
+                assert np.array_equal(getattr(out, col).cpu().numpy(), getattr(e, col)), (mode, len(pt), col)
+            assert np.array_equal(cp.cpu().numpy(), e.x), (mode, len(pt), "join")
+            assert np.array_equal(out.ct.cpu().numpy(), e.ct)
+            if pbk:
+                k = oracle.key_schedule_witness(keys, layout=ol.PACKED)
+                for col in ("w", "kx", "ky", "kz"):
+                    assert np.array_equal(getattr(out.key, col).cpu().numpy(), getattr(k, col)), (mode, col)
+    with pytest.raises(Exception):
+        c.set_option("batch_streams", 9)
+    c.close()
+
+
+def test_batches_entry_point_captures_into_one_graph(pkg, oracle):
+    """The internal streams join a capture of the caller's stream through the fork / join events: one hipGraph holding six
+    batches on three streams replays byte-exactly (per-block keys)."""
+    import torch
+    c = pkg.Context(0)
+    rng = np.random.default_rng(600)
+    n = 5000
+    host, batches = [], []
+    for _ in range(6):
+        pt, keys = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, (n, 16), dtype=np.uint8)
+        host.append((pt, keys))
+        batches.append((torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda(), c.alloc_witness(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True, n_keys=n)))
+    c.encrypt_witness_batches(batches, True)  # creates the internal streams outside the capture
+    torch.cuda.synchronize()
+    for _, _, out in batches:
+        for t in (out.x, out.y, out.z, out.ct):
+            t.zero_()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        c.encrypt_witness_batches(batches, True)
+    torch.cuda.synchronize()
+    assert int(batches[0][2].x.max()) == 0  # captured, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    for (pt, keys), (_, _, out) in zip(host, batches):
+        e = oracle.encrypt_witness(pt, keys, layout=ol.PACKED)
+        for col in "xyz":
+            assert np.array_equal(getattr(out, col).cpu().numpy(), getattr(e, col)), col
+        assert np.array_equal(out.ct.cpu().numpy(), e.ct)
+    c.close()
+
+
 def test_concurrent_launches_on_one_context_are_byte_exact(pkg, oracle):
     """Independent batches may be issued on several streams of one context (bench.py "overlapped_batches": ramp and tail of a
     launch then overlap its neighbours).  Twelve launches -- per-block keys, shared key by pointer and the scheduled key, each

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Independent batches on 1 / 2 / 3 streams of one hipGraph (bench.overlapped_launches): microseconds per launch.
+"""Independent batches through aesw_encrypt_witness_batches_device on 1 / 2 / 3 internal streams, captured into one hipGraph
+(bench.overlapped_launches): microseconds per batch.
 argv: log2(blocks) [pbk].  Round 3: a 2^16-block launch costs 35 us alone and 29 us when its ramp and tail overlap its
 neighbours' bodies -- the time of a linear fill of its bytes."""
 import sys
