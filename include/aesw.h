@@ -182,7 +182,12 @@ int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout,
 /* d_keys: n*16 B when per_block_keys; 16 B (one key, expanded inside the call)
  * or NULL (use the key of aesw_schedule_key*; AESW_ERR_NO_KEY if there is none,
  * where the reference panics "Keys should be scheduled") otherwise.
- * d_ct and d_key_slab are optional (NULL). */
+ * d_ct and d_key_slab are optional (NULL).
+ * Alignment: every output pointer must be 16-byte aligned (AESW_ERR_INVALID_ARG otherwise) and SHOULD be 128-byte aligned:
+ * a wave writes whole 128-byte lines of its 16-block range, and a base that is only 16-byte aligned makes every one of them
+ * straddle two lines -- 76 us instead of 40 for a 2^16-block launch (64-byte aligned: 44; beyond 128 nothing more;
+ * examples/aesw_batches.c with AESW_EXAMPLE_ALIGN).  hipMalloc, aesw_columns_alloc (2 MiB) and torch tensors are aligned;
+ * sub-ranges of one buffer at b * n * stride offsets are not, unless n is a multiple of 8. */
 int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys,
                                 int per_block_keys, uint64_t n, int layout, uint8_t *d_x,
                                 uint8_t *d_y, uint8_t *d_z, uint8_t *d_ct,
