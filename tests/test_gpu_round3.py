@@ -460,5 +460,5 @@ def test_batches_from_plain_c(pkg, tmp_path):
     out = subprocess.run([str(exe), "15", "12"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
     ratio = float(re.search(r"three streams / one stream = ([0-9.]+)", out.stdout).group(1))
-    assert ratio < 1.05, out.stdout
+    assert ratio < 1.10, out.stdout
 
