@@ -11,6 +11,8 @@ the generated tables against the text of constant.rs (fixture in tests/golden).
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 
 AES_ROWS = 1360            # src/constant.rs:114
@@ -39,7 +41,17 @@ def _gf_mul(a: int, b: int) -> int:
     return r
 
 
+@functools.lru_cache(maxsize=None)
+def _sbox_fips_bytes() -> bytes:
+    """The GF(2^8) inverse search takes ~25 - 45 ms in Python: done once per process."""
+    return _sbox_fips_compute().tobytes()
+
+
 def _sbox_fips() -> np.ndarray:
+    return np.frombuffer(_sbox_fips_bytes(), dtype=np.uint8).copy()
+
+
+def _sbox_fips_compute() -> np.ndarray:
     inv = [0] * 256
     for x in range(1, 256):
         for y in range(1, 256):
