@@ -630,7 +630,17 @@ def main():
             dt_direct = time.perf_counter() - t0
             pkg.api.host_free(whole)
             del whole
+            # ... and into an ordinary (pageable) array: every column crosses the bounce buffer, moved on by copy_threads threads
+            plain = np.empty(16 * (32 << k), np.uint8)
+            ctx.assemble_advice_host(k, n_sets, wit, kw, nn, plain, layout=pkg.LAYOUT_PACKED, as_fr=True)
+            t0 = time.perf_counter()
+            ctx.assemble_advice_host(k, n_sets, wit, kw, nn, plain, layout=pkg.LAYOUT_PACKED, as_fr=True)
+            dt_plain = time.perf_counter() - t0
+            del plain
             extras["fr_columns_to_host"] = {
+                "direct_pageable": {"seconds": dt_plain, "blocks_per_s": nn / dt_plain, "GBps_to_host": 16 * (32 << k) / dt_plain / 1e9,
+                                    "copy_threads": ctx.get_option("effective_copy_threads"),
+                                    "note": "aesw_assemble_advice_host into an ordinary numpy array"},
                 "direct_pinned": {"seconds": dt_direct, "blocks_per_s": nn / dt_direct, "GBps_to_host": 16 * (32 << k) / dt_direct / 1e9,
                                   "note": "aesw_assemble_advice_host into one page-locked buffer (aesw_host_alloc / aesw_host_register): no consumer copy"},
                 "circuit": "K=20, N=5: 16 advice columns x 2^20 Fr cells (512 MiB), %d blocks" % nn,
