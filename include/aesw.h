@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define AESW_VERSION 100 /* 0.1.0 */
+#define AESW_VERSION 101 /* 0.1.1: + aesw_columns_alloc / _free, aesw_encrypt_witness_batches_device, aesw_batch */
 
 #define AESW_AES_ROWS 1360u          /* src/constant.rs:114 */
 #define AESW_KEY_SCHEDULE_ROWS 1760u /* src/constant.rs:113 (capacity constant only) */

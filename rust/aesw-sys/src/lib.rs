@@ -11,7 +11,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const AESW_VERSION: c_int = 100;
+pub const AESW_VERSION: c_int = 101;
 
 pub const AESW_AES_ROWS: u32 = 1360; // src/constant.rs:114
 pub const AESW_KEY_SCHEDULE_ROWS: u32 = 1760; // src/constant.rs:113
