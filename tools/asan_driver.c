@@ -172,6 +172,61 @@ int main(void) {
         CHECK(aesw_host_key_circuit_run(ctx, 12, key, &hc));
         aesw_host_circuit_free(hc);
     }
+    {   /* round 3: the probed arena (virtual-memory candidates, whole sets and single columns), a launch into it, and the batch
+         * entry point on 1 and 3 internal streams; compared with the host-pointer path */
+        const uint64_t na = (1u << 16) + 48, nbat = 5, nsm = 700;
+        uint8_t *hp = malloc(na * 16), *hk = malloc(na * 16), *d_p, *d_kk;
+        for (uint64_t i = 0; i < na * 16; ++i) { hp[i] = (uint8_t)(i * 7 + 1); hk[i] = (uint8_t)(i * 13 + 5); }
+        HCHECK(hipMalloc((void **)&d_p, na * 16));
+        HCHECK(hipMalloc((void **)&d_kk, na * 16));
+        HCHECK(hipMemcpy(d_p, hp, na * 16, hipMemcpyHostToDevice));
+        HCHECK(hipMemcpy(d_kk, hk, na * 16, hipMemcpyHostToDevice));
+        const size_t sx = aesw_column_stride(AESW_LAYOUT_PACKED, 0);
+        uint8_t *ref_x = malloc(na * sx), *ref_y = malloc(na * 1056), *ref_z = malloc(na * 608), *got_x = malloc(na * sx);
+        CHECK(aesw_encrypt_witness(ctx, hp, hk, 1, na, AESW_LAYOUT_PACKED, ref_x, ref_y, ref_z, NULL, NULL));
+        for (int unit = 0; unit < 3; ++unit) {
+            CHECK(aesw_set_option(ctx, "arena_unit", unit));
+            CHECK(aesw_set_option(ctx, "arena_probe", 2));
+            aesw_columns cols;
+            CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 1, 1, &cols));
+            if (!cols.x || !cols.key.kz || !cols.ct || cols.candidates == 0) { fprintf(stderr, "arena: members missing\n"); return 1; }
+            CHECK(aesw_encrypt_witness_device(ctx, d_p, d_kk, 1, na, AESW_LAYOUT_PACKED, cols.x, cols.y, cols.z, cols.ct, &cols.key, NULL));
+            HCHECK(hipMemcpy(got_x, cols.x, na * sx, hipMemcpyDeviceToHost));
+            if (memcmp(got_x, ref_x, na * sx) != 0) { fprintf(stderr, "arena unit %d: x differs\n", unit); return 1; }
+            CHECK(aesw_columns_free(ctx, &cols));
+        }
+        CHECK(aesw_set_option(ctx, "arena_unit", 2));
+        CHECK(aesw_set_option(ctx, "arena_probe", -1));
+        {
+            aesw_columns kc;  /* key slabs alone */
+            CHECK(aesw_columns_alloc(ctx, 1000, AESW_LAYOUT_PACKED, 2, 0, &kc));
+            if (kc.x || !kc.key.w) { fprintf(stderr, "key-only arena: wrong members\n"); return 1; }
+            CHECK(aesw_columns_free(ctx, &kc));
+        }
+        aesw_batch bt[5];
+        uint8_t *d_o[3];
+        const size_t pitch[3] = {(nsm * 1360 + 127) / 128 * 128, (nsm * 1056 + 127) / 128 * 128, (nsm * 608 + 127) / 128 * 128};
+        for (int c = 0; c < 3; ++c) HCHECK(hipMalloc((void **)&d_o[c], nbat * pitch[c]));
+        for (uint64_t i = 0; i < nbat; ++i) {
+            bt[i].d_pt = d_p + i * nsm * 16; bt[i].d_keys = d_kk + i * nsm * 16; bt[i].n = nsm;
+            bt[i].d_x = d_o[0] + i * pitch[0]; bt[i].d_y = d_o[1] + i * pitch[1]; bt[i].d_z = d_o[2] + i * pitch[2];
+            bt[i].d_ct = NULL; bt[i].d_key_slab = NULL;
+        }
+        for (int ns = 1; ns <= 3; ns += 2) {
+            CHECK(aesw_set_option(ctx, "batch_streams", ns));
+            HCHECK(hipMemset(d_o[0], 0, nbat * pitch[0]));
+            CHECK(aesw_encrypt_witness_batches_device(ctx, bt, (uint32_t)nbat, 1, AESW_LAYOUT_PACKED, NULL));
+            HCHECK(hipDeviceSynchronize());
+            for (uint64_t i = 0; i < nbat; ++i) {
+                HCHECK(hipMemcpy(got_x, d_o[0] + i * pitch[0], nsm * sx, hipMemcpyDeviceToHost));
+                if (memcmp(got_x, ref_x + i * nsm * sx, nsm * sx) != 0) { fprintf(stderr, "batches (%d streams): batch %llu differs\n", ns, (unsigned long long)i); return 1; }
+            }
+        }
+        if (aesw_encrypt_witness_batches_device(ctx, NULL, 2, 1, AESW_LAYOUT_PACKED, NULL) != AESW_ERR_INVALID_ARG) { fprintf(stderr, "batches: NULL accepted\n"); return 1; }
+        for (int c = 0; c < 3; ++c) HCHECK(hipFree(d_o[c]));
+        HCHECK(hipFree(d_p)); HCHECK(hipFree(d_kk));
+        free(hp); free(hk); free(ref_x); free(ref_y); free(ref_z); free(got_x);
+    }
     aesw_destroy(ctx);
     free(pt); free(keys);
     printf("asan driver: ok\n");
