@@ -100,6 +100,95 @@ const char *aesw_strerror(int status) {
     }
 }
 
+// ---- the scheduled key's round-key slots (aesw_ctx.h) ----------------------------------------------------------
+namespace {
+constexpr size_t KEY_CHUNK_SLOTS = 16, KEY_SLOT_BYTES = 256, KEY_MAX_READERS = 16;
+
+bool stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+// While some stream of this thread is being captured (global mode), allocation calls are refused: run them relaxed.
+struct RelaxedCapture {
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    bool on;
+    RelaxedCapture() { on = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!on) (void)hipGetLastError(); }
+    ~RelaxedCapture() { if (on && hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
+};
+
+// A slot nobody has used yet (fresh memory; a new chunk every KEY_CHUNK_SLOTS slots).
+int key_new_slot(aesw_ctx *ctx, int *out) {
+    RelaxedCapture relaxed;
+    const size_t used = ctx->key_slots.size();
+    if (used == ctx->key_chunks.size() * KEY_CHUNK_SLOTS) {
+        uint8_t *c = nullptr;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&c), KEY_CHUNK_SLOTS * KEY_SLOT_BYTES));
+        ctx->key_chunks.push_back(c);
+    }
+    aesw_ctx::KeySlot sl;
+    sl.d = ctx->key_chunks.back() + (used % KEY_CHUNK_SLOTS) * KEY_SLOT_BYTES;
+    HIP_TRY(ctx, hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
+    ctx->key_slots.push_back(sl);
+    *out = (int)used;
+    return AESW_OK;
+}
+
+// The slot an un-captured schedule writes next: the ring's next slot (spare slots and fresh ones fill the ring up to
+// "key_slots"; a slot a capture has pinned meanwhile is replaced).  The caller waits for the slot's readers.
+int key_next_ring_slot(aesw_ctx *ctx, int *out) {
+    auto &ring = ctx->key_ring_slots;
+    while ((int)ring.size() > ctx->key_ring) { ctx->key_spare.push_back(ring.back()); ring.pop_back(); }
+    auto take = [&](int *idx) -> int {
+        while (!ctx->key_spare.empty()) {
+            const int i = ctx->key_spare.back();
+            ctx->key_spare.pop_back();
+            if (!ctx->key_slots[i].pinned) { *idx = i; return AESW_OK; }
+        }
+        return key_new_slot(ctx, idx);
+    };
+    if ((int)ring.size() < ctx->key_ring) {
+        int idx = -1;
+        const int rc = take(&idx);
+        if (rc != AESW_OK) return rc;
+        ring.push_back(idx);
+        ctx->key_pos = (int)ring.size() - 1;
+    } else {
+        ctx->key_pos = (ctx->key_pos + 1) % (int)ring.size();
+        if (ctx->key_slots[ring[ctx->key_pos]].pinned) {
+            int idx = -1;
+            const int rc = take(&idx);
+            if (rc != AESW_OK) return rc;
+            ring[ctx->key_pos] = idx;
+        }
+    }
+    *out = ring[ctx->key_pos];
+    return AESW_OK;
+}
+
+// An un-captured launch on `s` reads slot `sl`: the schedule that reuses the slot will wait for it.  One event per distinct
+// stream: a stream's later record is ordered behind its earlier launches, so re-recording loses nobody.
+int key_track_reader(aesw_ctx *ctx, aesw_ctx::KeySlot &sl, hipStream_t s) {
+    for (auto &r : sl.readers)
+        if (r.s == s) { HIP_TRY(ctx, hipEventRecord(r.e, s)); return AESW_OK; }
+    if (sl.readers.size() >= KEY_MAX_READERS) {
+        // fold the oldest reader into this stream: `s` waits for it BEHIND the launch just issued, so the event recorded
+        // next on `s` stands for both
+        HIP_TRY(ctx, hipStreamWaitEvent(s, sl.readers.front().e, 0));
+        ctx->event_pool.push_back(sl.readers.front().e);
+        sl.readers.erase(sl.readers.begin());
+    }
+    hipEvent_t e = nullptr;
+    if (!ctx->event_pool.empty()) { e = ctx->event_pool.back(); ctx->event_pool.pop_back(); }
+    else HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const hipError_t rc = hipEventRecord(e, s);
+    if (rc != hipSuccess) { ctx->event_pool.push_back(e); return fail_hip(ctx, rc, "hipEventRecord(key reader)"); }
+    sl.readers.push_back(aesw_ctx::KeyReader{s, e});
+    return AESW_OK;
+}
+}  // namespace
+
 const char *aesw_last_error(const aesw_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
 int aesw_device_count(int *count) {
@@ -140,7 +229,6 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
     };
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_tables), 768), "hipMalloc(tables)");
     T(hipMalloc(reinterpret_cast<void **>(&ctx->d_fr_lut), sizeof lut), "hipMalloc(fr_lut)");
-    T(hipMalloc(reinterpret_cast<void **>(&ctx->d_rk), 256), "hipMalloc(rk)");
     // the flush schedules depend on the layout only: searched once per process (~20 ms each), uploaded per context
     static std::vector<uint32_t> host_ftab[3];
     static std::once_flag ftab_once;
@@ -155,8 +243,7 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
         T(hipMalloc(reinterpret_cast<void **>(&ctx->d_ftab[l]), ft.size() * sizeof(uint32_t)), "hipMalloc(flush table)");
         if (rc == AESW_OK) T(hipMemcpy(ctx->d_ftab[l], ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(flush table)");
     }
-    T(hipEventCreateWithFlags(&ctx->key_ready, hipEventDisableTiming), "hipEventCreate(key_ready)");
-    T(hipEventCreateWithFlags(&ctx->key_last_use, hipEventDisableTiming), "hipEventCreate(key_last_use)");
+    if (rc == AESW_OK) { int first = -1; rc = key_new_slot(ctx, &first); if (rc == AESW_OK) ctx->key_spare.push_back(first); }  // the first chunk of round-key slots
     if (rc == AESW_OK) T(warm_launch_attributes(), "hipFuncSetAttribute(max dynamic LDS)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_fr_lut, lut, sizeof lut, hipMemcpyHostToDevice), "hipMemcpy(fr_lut)");
@@ -186,11 +273,14 @@ void aesw_destroy(aesw_ctx *ctx) {
             for (auto &r : a.ranges) { if (r.vmm) vmm_release_arena(r.p, r.bytes); else (void)hipFree(r.p); }
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
         if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
-        if (ctx->d_rk) (void)hipFree(ctx->d_rk);
+        for (auto &sl : ctx->key_slots) {
+            if (sl.ready) (void)hipEventDestroy(sl.ready);
+            for (auto &r : sl.readers) (void)hipEventDestroy(r.e);
+        }
+        for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+        for (uint8_t *c : ctx->key_chunks) (void)hipFree(c);
         for (uint32_t *t : ctx->d_ftab)
             if (t) (void)hipFree(t);
-        if (ctx->key_ready) (void)hipEventDestroy(ctx->key_ready);
-        if (ctx->key_last_use) (void)hipEventDestroy(ctx->key_last_use);
     }
     delete ctx;
 }
@@ -365,6 +455,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "chunk_blocks")) { if (value < 64) return AESW_ERR_INVALID_ARG; ctx->chunk_blocks = value; return AESW_OK; }
     if (!std::strcmp(name, "batch_streams")) { if (value < 1 || value > 8) return AESW_ERR_INVALID_ARG; ctx->batch_streams = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "copy_threads")) { if (value < -1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->copy_threads = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "key_slots")) { if (value < 1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->key_ring = (int)value; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
 }
 
@@ -432,6 +523,15 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "batch_streams")) { *value = ctx->batch_streams; return AESW_OK; }
     if (!std::strcmp(name, "copy_threads")) { *value = ctx->copy_threads; return AESW_OK; }
     if (!std::strcmp(name, "effective_copy_threads")) { *value = auto_copy_threads(ctx); return AESW_OK; }
+    if (!std::strcmp(name, "key_slots")) { *value = ctx->key_ring; return AESW_OK; }
+    if (!std::strcmp(name, "key_reader_waits")) { *value = (int64_t)ctx->key_waits; return AESW_OK; }  // read-only statistics
+    if (!std::strcmp(name, "key_slots_allocated")) { *value = (int64_t)ctx->key_slots.size(); return AESW_OK; }
+    if (!std::strcmp(name, "key_slots_pinned")) {
+        int64_t n = 0;
+        for (const auto &sl : ctx->key_slots) n += sl.pinned ? 1 : 0;
+        *value = n;
+        return AESW_OK;
+    }
     return AESW_ERR_INVALID_ARG;
 }
 
@@ -466,17 +566,40 @@ int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, co
     }
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
-    KeyParams kp{d_key, ctx->d_tables, ko, ctx->d_rk, 1, 0, 0};
-    {   // write-after-read: launches on OTHER streams may still be reading the previous key's round keys
-        hipStream_t ks_ = reinterpret_cast<hipStream_t>(stream);
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(ks_, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-        if (ctx->key_used && cs == hipStreamCaptureStatusNone) HIP_TRY(ctx, hipStreamWaitEvent(ks_, ctx->key_last_use, 0));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool cap = stream_capturing(s);
+    int slot = -1;
+    if (cap) {
+        // a captured schedule writes its slot on every replay of the graph, whenever that is: a slot of its own, never reused
+        const int rc = key_new_slot(ctx, &slot);
+        if (rc != AESW_OK) return rc;
+        ctx->key_slots[slot].pinned = true;
+    } else {
+        const int rc = key_next_ring_slot(ctx, &slot);
+        if (rc != AESW_OK) return rc;
+        // write-after-read: every launch that may still read this slot's previous key, on whatever stream, comes first
+        aesw_ctx::KeySlot &sl = ctx->key_slots[slot];
+        hipError_t e = hipSuccess;
+        for (auto &r : sl.readers) {
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, r.e, 0);
+            if (e != hipSuccess) break;
+            ++ctx->key_waits;
+        }
+        if (e != hipSuccess) {
+            // keep the readers: the slot has not been written, and the ring must come back to it with them intact
+            ctx->key_pos = (ctx->key_pos + (int)ctx->key_ring_slots.size() - 1) % (int)ctx->key_ring_slots.size();
+            return fail_hip(ctx, e, "hipStreamWaitEvent(key readers)");
+        }
+        for (auto &r : sl.readers) ctx->event_pool.push_back(r.e);
+        sl.readers.clear();
     }
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, 0u, reinterpret_cast<hipStream_t>(stream)));
+    aesw_ctx::KeySlot &sl = ctx->key_slots[slot];
+    KeyParams kp{d_key, ctx->d_tables, ko, sl.d, 1, 0, 0};
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, 0u, s));
     // a later encrypt on ANOTHER stream (the host-pointer entry points use the context's own) waits for these round keys
-    HIP_TRY(ctx, hipEventRecord(ctx->key_ready, reinterpret_cast<hipStream_t>(stream)));
-    ctx->key_stream = stream;
+    if (!cap) HIP_TRY(ctx, hipEventRecord(sl.ready, s));
+    sl.writer = s;
+    ctx->key_cur = slot;
     ctx->have_key = true;
     return AESW_OK;
 }
@@ -513,32 +636,38 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
         HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, 0u, s));
     }
     const int km = per_block_keys ? 0 : (d_keys ? 1 : 2);
-    if (km == 2 && stream != ctx->key_stream) {
-        // the round keys were written on another stream: order this launch behind them.  While a stream is being
-        // captured the wait would pull the key stream into the capture; capture on the stream the key was scheduled on.
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-        if (cs != hipStreamCaptureStatusNone) {
-            // a captured launch that reads the scheduled round keys with no dependency on the launch that writes them
-            // would race on replay: refuse instead of dropping the wait silently
-            ctx->last_error = "scheduled-key encrypt captured on a stream other than the one aesw_schedule_key_device ran on";
-            return AESW_ERR_INVALID_ARG;
-        }
-        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->key_ready, 0));
+    const bool cap = km == 2 && stream_capturing(s);
+    if (km == 2 && s != ctx->key_slots[ctx->key_cur].writer) {
+        // the round keys were written on another stream: order this launch behind them
+        aesw_ctx::KeySlot &sl = ctx->key_slots[ctx->key_cur];
+        if (cap) {
+            // a captured launch cannot take a dependency on work outside its graph.  If the key launch has already finished,
+            // there is nothing to depend on; otherwise refuse instead of dropping the wait silently
+            RelaxedCapture relaxed;
+            const bool done = !sl.pinned && hipEventQuery(sl.ready) == hipSuccess;
+            (void)hipGetLastError();
+            if (!done) {
+                ctx->last_error = "scheduled-key encrypt captured on a stream other than the one aesw_schedule_key_device ran on, "
+                                  "and the key launch has not finished (or was itself captured): synchronise first, or capture both on one stream";
+                return AESW_ERR_INVALID_ARG;
+            }
+        } else if (!sl.pinned) {
+            HIP_TRY(ctx, hipStreamWaitEvent(s, sl.ready, 0));
+        }  // (a slot written by a captured schedule has no event: the caller orders its graph launches, include/aesw.h)
     }
-    EncParams p{d_pt, d_keys, reinterpret_cast<const uint32_t *>(ctx->d_rk), ctx->d_tables, ctx->d_ftab[layout], d_x, d_y, d_z, d_ct,
+    EncParams p{d_pt, d_keys, km == 2 ? reinterpret_cast<const uint32_t *>(ctx->key_slots[ctx->key_cur].d) : nullptr, ctx->d_tables, ctx->d_ftab[layout], d_x, d_y, d_z, d_ct,
                 per_block_keys ? ko : KeyOut{nullptr, nullptr, nullptr, nullptr}, n, 0, 0};
 #ifdef AESW_TRACE
     p.trace = ctx->trace;
 #endif
     HIP_TRY(ctx, launch_encrypt(p, layout, ctx->xt, km, per_block_keys && kemit, auto_waves(ctx, layout, per_block_keys != 0),
                                 ctx->nt, (uint32_t)ctx->grid_cap, ctx->xcd_remap, (uint32_t)ctx->lds_pad, s));
-    if (km == 2) {  // this launch reads the scheduled round keys: the next aesw_schedule_key_device must not overwrite them under it
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-        if (cs == hipStreamCaptureStatusNone) {
-            HIP_TRY(ctx, hipEventRecord(ctx->key_last_use, s));
-            ctx->key_used = true;
+    if (km == 2) {  // this launch reads the current slot: nothing may overwrite the slot under it
+        aesw_ctx::KeySlot &sl = ctx->key_slots[ctx->key_cur];
+        if (cap) sl.pinned = true;  // read on every replay of the graph, whenever that is: the ring never reuses the slot
+        else {
+            const int rc = key_track_reader(ctx, sl, s);
+            if (rc != AESW_OK) return rc;
         }
     }
     return AESW_OK;

@@ -13,13 +13,32 @@ struct aesw_ctx {
     int device = -1;
     uint8_t *d_tables = nullptr;  // 768 B
     uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
-    uint8_t *d_rk = nullptr;      // 176 B: round keys of the key given to aesw_schedule_key*
     uint32_t *d_ftab[3] = {nullptr, nullptr, nullptr};  // flush descriptors per layout (aesw_layout.h "scheduled flush")
+    // The scheduled key (FixedAes128Config::schedule_key, src/aes128.rs:143-152: `self.keys = Some(..)` replaces the key between
+    // encrypt calls).  Round keys live in SLOTS of 256 B (176 used); every aesw_schedule_key_device takes the next slot of a small
+    // ring and every scheduled-key launch bakes the pointer of the slot that is current when it is ENQUEUED, so a launch never sees
+    // a later key.  A slot is rewritten only behind every launch that reads it: one event per distinct reader stream (re-recorded
+    // by that stream's later launches, which are ordered behind its earlier ones), all of them waited on by the schedule that
+    // reuses the slot.  Slots a hipGraph capture has touched (a captured schedule writes one, a captured launch reads one on every
+    // replay) are PINNED: the ring never hands them out again.
+    struct KeyReader { hipStream_t s; hipEvent_t e; };
+    struct KeySlot {
+        uint8_t *d = nullptr;
+        bool pinned = false;
+        hipEvent_t ready = nullptr;  // recorded behind the key launch that wrote the slot: launches on other streams wait on it
+        hipStream_t writer = nullptr;
+        std::vector<KeyReader> readers;  // launches that may still be reading the slot
+    };
+    std::vector<KeySlot> key_slots;
+    std::vector<uint8_t *> key_chunks;   // hipMalloc'ed backing of the slots (KEY_CHUNK_SLOTS each)
+    std::vector<hipEvent_t> event_pool;  // reader events not in use
+    std::vector<int> key_ring_slots;     // the ring: indices into key_slots, at most key_ring of them
+    std::vector<int> key_spare;          // slots taken out of the ring when "key_slots" shrank (their readers are still tracked)
+    int key_pos = 0;        // ring position of the slot the last eager schedule wrote
+    int key_cur = -1;       // slot of the current key (-1: none scheduled)
+    int key_ring = 4;       // option "key_slots": un-pinned slots the ring cycles through (1 = every schedule waits for all readers)
+    uint64_t key_waits = 0;  // statistics: reader events a schedule had to wait on (option "key_reader_waits", read-only)
     bool have_key = false;
-    void *key_stream = nullptr;      // the stream the scheduled key's round keys were written on
-    hipEvent_t key_ready = nullptr;  // recorded behind the key launch of aesw_schedule_key_device: other streams wait on it
-    hipEvent_t key_last_use = nullptr;  // recorded behind every launch that READS the scheduled round keys: the next aesw_schedule_key_device waits on it
-    bool key_used = false;
     bool xt = false;
     int waves_shared = 0;  // waves per group, shared-key kernels (0 = auto)
     int waves_pbk = 0;     // per-block-key and key kernels (0 = auto)

@@ -167,13 +167,30 @@ int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]);
  * aesw_encrypt_witness_device(..., d_keys = NULL, per_block_keys = 0) calls,
  * and optionally emits its key-schedule witness (one key slab).  This is the
  * reference's call shape: schedule_key once, encrypt many times
- * (benches/aes128.rs:50-53).  The round keys are written on `stream`: later
- * an encrypt call on another stream is ordered behind them with an event (no host wait).  The
- * context holds ONE scheduled key: scheduling another key is ordered behind the launches that still read the
- * previous one on other streams (an event recorded behind every scheduled-key launch; launches inside a
- * hipGraph capture are not tracked: synchronise before re-scheduling under a captured graph).  Inside a hipGraph capture the
- * scheduled-key encrypt must be captured on the stream the key was scheduled on: on any other stream the
- * call returns AESW_ERR_INVALID_ARG (the dependency on the round keys could not be captured).
+ * (benches/aes128.rs:50-53).
+ *
+ * What is guaranteed (the reference's `self.keys = Some(..)`, src/aes128.rs:143-152, replaces the key atomically between
+ * encrypt calls; here "between" means HOST CALL ORDER on the context, whatever streams the calls name):
+ *  - A scheduled-key launch (d_keys = NULL) uses the key of the last aesw_schedule_key* call that RETURNED before the launch
+ *    was enqueued -- never a later one, even if the later schedule's kernel runs first or concurrently on another stream: round
+ *    keys live in slots, a schedule takes the next slot of a ring ("key_slots", default 4) and the launch keeps the pointer of
+ *    the slot that was current at enqueue time.
+ *  - The launch is ordered behind the key kernel that fills its slot (same stream: stream order; another stream: an event, no
+ *    host wait).
+ *  - A slot is rewritten only behind EVERY launch that reads it, on any number of streams, including the internal streams of
+ *    aesw_encrypt_witness_batches_device: one event per distinct reader stream since the slot was written, all of them waited on
+ *    (on the scheduling stream, no host wait) by the schedule that takes the slot again.  More than 16 distinct reader streams
+ *    per slot are folded (the 17th stream waits for the first one's launches AFTER its own launch).  Streams that carried
+ *    scheduled-key launches may be destroyed at any time (hipStreamDestroy drains them).
+ *  - Under hipGraph capture nothing can be tracked per replay, so slots are frozen instead: a schedule captured into a graph
+ *    writes a slot of its own, and a slot read by a captured launch is pinned -- in both cases the ring never hands that slot
+ *    out again (256 B each, until aesw_destroy).  A captured launch therefore reads, on every replay, the key that was current
+ *    when it was CAPTURED; re-scheduling on the context does not change what an existing graph encrypts with, and needs no
+ *    synchronisation with its replays.  What remains the caller's: a graph that contains a schedule must be launched (and
+ *    ordered, by the caller) before un-captured launches that are to read that key run.
+ *  - A scheduled-key launch captured on a stream OTHER than the one its key was scheduled on cannot take a dependency on the
+ *    key kernel: it is accepted when that kernel has already finished (synchronise first) and refused with
+ *    AESW_ERR_INVALID_ARG otherwise, or when the schedule itself was captured on another stream.
  * All launch attributes (dynamic LDS sizes) are set by aesw_create(): launches never change function
  * attributes, so every *_device entry point may be captured into a hipGraph
  * (hipStreamBeginCapture on `stream`) and replayed. */
@@ -390,7 +407,8 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * "store_mode" (0 plain, 1 nontemporal: the default, 2 write-through sc1), "nt_stores" (0/1), "grid_cap" (max workgroups per launch,
  * 0 = one per block group), "xcd_remap" (which block groups the workgroups of one XCD take: 0 = dispatch order, 1 = one contiguous eighth of
  * the block groups per XCD (default), C >= 2 = the XCDs take turns in chunks of C groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
- * pipeline, default 2^15), "batch_streams" (internal streams of aesw_encrypt_witness_batches_device, 1 ... 8, default 3), "copy_threads" (host threads that move a stage from the page-locked bounce buffer into a PAGEABLE destination;
+ * pipeline, default 2^15), "batch_streams" (internal streams of aesw_encrypt_witness_batches_device, 1 ... 8, default 3), "key_slots" (round-key slots
+ * aesw_schedule_key* cycles through, 1 ... 64, default 4; with 1 every schedule waits for all launches reading the previous key), "copy_threads" (host threads that move a stage from the page-locked bounce buffer into a PAGEABLE destination;
  * -1 = auto: a quarter of the CPUs the process may run on, 1 ... 4; page-locked destinations receive the DMA directly and use none), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB
  * workgroups: the default, 2 one-shot 16 KiB), "assemble_geometry" (Fr form of aesw_assemble_advice_*: 0 striding workgroups,
@@ -401,7 +419,8 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * backs: 0 = the whole set of columns in one range; 1 = one column, placed greedily, largest first; 2 = whole sets first, then
  * columns if no whole-set candidate ran the pattern as fast as its fill: the default).
  * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
- * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied), and "effective_copy_threads".
+ * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied), and "effective_copy_threads", and the
+ * read-only statistics "key_reader_waits" (reader events schedules have waited on), "key_slots_allocated", "key_slots_pinned".
  * Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);

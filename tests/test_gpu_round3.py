@@ -97,7 +97,7 @@ def test_every_settable_option_reads_back(pkg):
     c = pkg.Context(0)
     for name, value in (("waves_shared", 2), ("waves_pbk", 3), ("store_mode", 1), ("key_store_mode", 2), ("fr_store_mode", 0),
                         ("fr_geometry", 2), ("grid_cap", 512), ("xcd_remap", 0), ("xcd_remap", 64), ("lds_pad", 4096), ("arena_align_log2", 16), ("arena_probe", 3), ("arena_unit", 1),
-                        ("chunk_blocks", 4096)):
+                        ("chunk_blocks", 4096), ("key_slots", 7), ("batch_streams", 5), ("copy_threads", 2)):
         c.set_option(name, value)
         assert c.get_option(name) == value, name
     c.set_option("force_table_path", 1)
@@ -112,41 +112,7 @@ def test_every_settable_option_reads_back(pkg):
     c.close()
 
 
-def test_scheduled_key_capture_on_a_foreign_stream_is_refused(pkg, oracle):
-    """A scheduled-key launch captured on a stream other than the key's would replay without a dependency on the round
-    keys: the C ABI returns AESW_ERR_INVALID_ARG instead of dropping the wait silently; captured on the
-    key's own stream it works and replays byte-exact."""
-    import torch
-    c = pkg.Context(0)
-    rng = np.random.default_rng(77)
-    n = 500
-    pt, key = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)
-    dpt, dkey = torch.from_numpy(pt).cuda(), torch.from_numpy(key).cuda()
-    c.schedule_key(dkey, key_slab=False)  # on torch's current (default) stream
-    torch.cuda.synchronize()
-    out = c.alloc_witness(n, pkg.LAYOUT_PACKED)
-    other = torch.cuda.Stream()
-    graph = torch.cuda.CUDAGraph()
-    with pytest.raises(pkg.AeswError) as ei:
-        with torch.cuda.graph(graph, stream=other):
-            c.encrypt_witness(dpt, None, out=out)
-    assert ei.value.status == pkg.api.ERR_INVALID_ARG and "captured" in str(ei.value)
-    # the documented way: schedule on the capture stream, then capture there
-    cap = torch.cuda.Stream()
-    with torch.cuda.stream(cap):
-        c.schedule_key(dkey, key_slab=False)
-    cap.synchronize()
-    graph2 = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph2, stream=cap):
-        c.encrypt_witness(dpt, None, out=out)
-    for t in (out.x, out.y, out.z):
-        t.fill_(0)
-    graph2.replay()
-    torch.cuda.synchronize()
-    e = oracle.encrypt_witness(pt, key, layout=ol.PACKED)
-    for col in "xyz":
-        assert np.array_equal(getattr(out, col).cpu().numpy(), getattr(e, col)), col
-    c.close()
+# (test_scheduled_key_capture_on_a_foreign_stream_is_refused moved to tests/test_gpu_round4.py with round 4's semantics)
 
 
 def test_probed_arena_2p22_blocks_per_block_keys_columns_beyond_4_gib(pkg, oracle):
