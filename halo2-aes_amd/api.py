@@ -340,6 +340,11 @@ Witness = namedtuple("Witness", "x y z ct key")
 KeyWitness = namedtuple("KeyWitness", "w kx ky kz rk")
 
 
+class ArenaWitness(Witness):
+    """A Witness whose tensors are views of an arena of aesw_columns_alloc; `.columns` is the aesw_columns handle it is
+    freed by (Context.free_columns), so slicing or replacing a member tensor cannot orphan the arena."""
+
+
 class Context:
     """One aesw_ctx: a device plus the host's three byte tables."""
 
@@ -430,9 +435,12 @@ class Context:
         return Witness(cols[0], cols[1], cols[2], ct, key)
 
     def alloc_columns(self, n: int, layout: int = K.LAYOUT_PACKED, want_ct: bool = False, key_slab: bool = False, key_only: bool = False):
-        """alloc_witness through the C ABI's arena (aesw_columns_alloc): ONE device allocation, every column on an
-        aligned boundary (option "arena_align_log2"; auto = 1 GiB for large batches).  The returned Witness's tensors
-        are views of that allocation, which lives until free_columns(witness) or the Context is closed."""
+        """alloc_witness through the C ABI's arena (aesw_columns_alloc): every column of the batch placed together, each on
+        a 2 MiB boundary.  From 2^16 blocks on the physical backing is chosen by measurement (option "arena_probe"; a shape
+        this context has placed and freed before comes out of its placement cache without a search, last_arena["candidates"]
+        == 0); with "arena_probe" 0 it is one hipMalloc with columns on 2^"arena_align_log2"-byte boundaries (that option is
+        ignored on the probed path).  The returned ArenaWitness's tensors are views of the arena, which lives until
+        free_columns(witness) or the Context is closed."""
         torch = self._torch()
         cols = Columns()
         if key_only:
@@ -452,17 +460,19 @@ class Context:
         if key_slab:
             key = KeyWitness(view(cols.key.w, n * K.WORDS_ROWS), *[view(getattr(cols.key, c), n * key_column_stride(layout, i))
                                                                    for i, c in enumerate(("kx", "ky", "kz"))], None)
-        wit = Witness(x, y, z, ct, key)
-        self._arenas[(key.w if key_only else y).data_ptr()] = cols
+        wit = ArenaWitness(x, y, z, ct, key)
+        wit.columns = cols
+        self._arenas[id(cols)] = cols
         self.last_arena = {"candidates": int(cols.candidates), "chosen": int(cols.chosen), "probe_us": float(cols.probe_us),
                            "fill_us": float(cols.fill_us), "bytes": int(cols.bytes)}
         return wit
 
     def free_columns(self, wit) -> None:
         """Release the arena behind a Witness from alloc_columns (its tensors must not be used afterwards)."""
-        cols = self._arenas.pop((wit.y if wit.y.numel() else wit.key.w).data_ptr(), None)
-        if cols is None:
+        cols = getattr(wit, "columns", None)
+        if cols is None or self._arenas.pop(id(cols), None) is None:
             raise ValueError("not a witness of alloc_columns (or already freed)")
+        wit.columns = None
         self._check(self._lib.aesw_columns_free(self._h, C.byref(cols)), "aesw_columns_free")
 
     # -- device entry points

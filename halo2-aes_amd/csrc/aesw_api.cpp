@@ -271,6 +271,7 @@ void aesw_destroy(aesw_ctx *ctx) {
         if (ctx->scratch) (void)hipFree(ctx->scratch);
         for (auto &a : ctx->vmm_arenas)
             for (auto &r : a.ranges) { if (r.vmm) vmm_release_arena(r.p, r.bytes); else (void)hipFree(r.p); }
+        aesw_arena_cache_trim(ctx, 0);
         if (ctx->d_tables) (void)hipFree(ctx->d_tables);
         if (ctx->d_fr_lut) (void)hipFree(ctx->d_fr_lut);
         for (auto &sl : ctx->key_slots) {
@@ -456,6 +457,19 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "batch_streams")) { if (value < 1 || value > 8) return AESW_ERR_INVALID_ARG; ctx->batch_streams = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "copy_threads")) { if (value < -1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->copy_threads = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "key_slots")) { if (value < 1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->key_ring = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "arena_cache")) {  // 0 also releases what is cached now
+        if (value != 0 && value != 1) return AESW_ERR_INVALID_ARG;
+        ctx->arena_cache_on = (int)value;
+        if (!value) aesw_arena_cache_trim(ctx, 0);
+        return AESW_OK;
+    }
+    if (!std::strcmp(name, "arena_cache_max_mb")) {
+        if (value < 0 || value > ((int64_t)1 << 30)) return AESW_ERR_INVALID_ARG;
+        ctx->arena_cache_max_bytes = (uint64_t)value << 20;
+        aesw_arena_cache_trim(ctx, ctx->arena_cache_max_bytes);
+        return AESW_OK;
+    }
+    if (!std::strcmp(name, "arena_probe_budget_ms")) { if (value < 0 || value > 600000) return AESW_ERR_INVALID_ARG; ctx->arena_probe_budget_ms = value; return AESW_OK; }
     return AESW_ERR_INVALID_ARG;
 }
 
@@ -524,6 +538,16 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "copy_threads")) { *value = ctx->copy_threads; return AESW_OK; }
     if (!std::strcmp(name, "effective_copy_threads")) { *value = auto_copy_threads(ctx); return AESW_OK; }
     if (!std::strcmp(name, "key_slots")) { *value = ctx->key_ring; return AESW_OK; }
+    if (!std::strcmp(name, "arena_cache")) { *value = ctx->arena_cache_on; return AESW_OK; }
+    if (!std::strcmp(name, "arena_cache_max_mb")) { *value = (int64_t)(ctx->arena_cache_max_bytes >> 20); return AESW_OK; }
+    if (!std::strcmp(name, "arena_probe_budget_ms")) { *value = ctx->arena_probe_budget_ms; return AESW_OK; }
+    if (!std::strcmp(name, "arena_cache_hits")) { *value = (int64_t)ctx->arena_cache_hits; return AESW_OK; }  // read-only statistics
+    if (!std::strcmp(name, "arena_cached_bytes")) {
+        uint64_t b = 0;
+        for (const auto &c : ctx->arena_cache) b += c.cols.bytes;
+        *value = (int64_t)b;
+        return AESW_OK;
+    }
     if (!std::strcmp(name, "key_reader_waits")) { *value = (int64_t)ctx->key_waits; return AESW_OK; }  // read-only statistics
     if (!std::strcmp(name, "key_slots_allocated")) { *value = (int64_t)ctx->key_slots.size(); return AESW_OK; }
     if (!std::strcmp(name, "key_slots_pinned")) {

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -59,6 +60,27 @@ void vmm_release(void *va, size_t total) {
     (void)hipMemAddressFree(va, total);
 }
 
+void release_ranges(const std::vector<aesw_ctx::ArenaRange> &ranges) {
+    for (const auto &r : ranges) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); }
+}
+
+uint64_t cache_bytes(const aesw_ctx *ctx) {
+    uint64_t b = 0;
+    for (const auto &a : ctx->arena_cache) b += a.cols.bytes;
+    return b;
+}
+
+// oldest entries out until at most `keep` bytes stay cached
+void cache_trim(aesw_ctx *ctx, uint64_t keep) {
+    while (!ctx->arena_cache.empty() && cache_bytes(ctx) > keep) {
+        size_t oldest = 0;
+        for (size_t i = 1; i < ctx->arena_cache.size(); ++i)
+            if (ctx->arena_cache[i].stamp < ctx->arena_cache[oldest].stamp) oldest = i;
+        release_ranges(ctx->arena_cache[oldest].ranges);
+        ctx->arena_cache.erase(ctx->arena_cache.begin() + (long)oldest);
+    }
+}
+
 }  // namespace
 
 int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab, int with_ct, aesw_columns *out) {
@@ -96,6 +118,30 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
         fill_out(raw + (align - reinterpret_cast<uintptr_t>(raw) % align) % align);
         return AESW_OK;
     }
+    // Placement cache: this context has placed (and the caller has freed) an arena of exactly this shape: take it over.  The
+    // backing is the one the earlier search chose, still mapped, so the pattern runs at the rate measured then.
+    if (ctx->arena_cache_on) {
+        for (size_t i = ctx->arena_cache.size(); i-- > 0;) {
+            aesw_ctx::ArenaRec &c = ctx->arena_cache[i];
+            if (c.n == n && c.layout == layout && c.with_key_slab == with_key_slab && c.with_ct == (with_ct ? 1 : 0) && c.xcd == ctx->xcd_remap) {
+                *out = c.cols;
+                out->candidates = 0;  // nothing was built or timed for this call; probe_us / fill_us are the earlier search's
+                ctx->vmm_arenas.push_back(std::move(c));
+                ctx->arena_cache.erase(ctx->arena_cache.begin() + (long)i);
+                ++ctx->arena_cache_hits;
+                return AESW_OK;
+            }
+        }
+        // a new shape: what is cached must not starve the search (it holds its losing candidates until it ends)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if (free_b < 2 * end + ((size_t)16 << 30)) cache_trim(ctx, 0);
+    }
+    const auto t_search = std::chrono::steady_clock::now();
+    auto over_budget = [&]() {
+        if (ctx->arena_probe_budget_ms <= 0) return false;
+        return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_search).count() > ctx->arena_probe_budget_ms;
+    };
     // Search by measurement.  A UNIT is what one candidate backs: the whole set of columns in one range ("arena_unit" 0), or
     // one column ("arena_unit" 1: greedy, largest column first).  For every unit up to `probe` candidates are built -- a plain
     // hipMalloc, then virtual ranges over physical chunks of 8 / 2 / 32 / 4 MiB, and round again --, the store-pattern
@@ -186,6 +232,7 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
             float best_probe = 0.f, best_fill = 1.f;
             float ref_fill = 0.f;  // the fastest linear fill seen for this unit: one slow fill sample must not make a candidate look good
             for (int k = 0; k < probe; ++k) {
+                if (best.p && over_budget()) break;  // "arena_probe_budget_ms": keep the best candidate so far
                 if (best.p) {  // the losers are held until the search ends: never let them take the device's last memory
                     size_t free_b = 0, total_b = 0;
                     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
@@ -252,7 +299,7 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     // search places the columns one at a time (the whole-set losers stay held meanwhile) and the better of the two is kept
     Placement pl = search(ctx->arena_unit == 1 ? 1 : 0);
     if (pl.rc != AESW_OK) return pl.rc;
-    if (ctx->arena_unit == 2 && n >= ((uint64_t)1 << 18) && pl.probe_us > accept * pl.fill_us) {
+    if (ctx->arena_unit == 2 && n >= ((uint64_t)1 << 18) && pl.probe_us > accept * pl.fill_us && !over_budget()) {
         Placement alt = search(1);
         if (alt.rc == AESW_OK && alt.probe_us / alt.fill_us < pl.probe_us / pl.fill_us) std::swap(pl, alt);
         for (auto &r : alt.ranges) losers.push_back(r);  // the search that lost (or failed half-way: already handed over)
@@ -267,10 +314,22 @@ int aesw_columns_alloc(aesw_ctx *ctx, uint64_t n, int layout, int with_key_slab,
     out->probe_us = pl.probe_us;
     out->fill_us = pl.fill_us;
     rec.key = out->base;
+    rec.n = n; rec.layout = layout; rec.with_key_slab = with_key_slab; rec.with_ct = with_ct ? 1 : 0; rec.xcd = ctx->xcd_remap;
+    rec.cols = *out;
     ctx->vmm_arenas.push_back(rec);
     done = true;
     return AESW_OK;  // ~Cleanup releases the candidates that were not chosen
 }
+
+}  // extern "C"
+
+// used by aesw_set_option("arena_cache" / "arena_cache_max_mb") and aesw_destroy (aesw_api.cpp)
+void aesw_arena_cache_trim(aesw_ctx *ctx, uint64_t keep_bytes) {
+    DeviceGuard g(ctx->device);
+    if (g.ok) cache_trim(ctx, keep_bytes);
+}
+
+extern "C" {
 
 int aesw_columns_free(aesw_ctx *ctx, aesw_columns *cols) {
     if (!ctx || !cols) return AESW_ERR_INVALID_ARG;
@@ -280,8 +339,17 @@ int aesw_columns_free(aesw_ctx *ctx, aesw_columns *cols) {
         bool vmm = false;
         for (size_t i = 0; i < ctx->vmm_arenas.size(); ++i)
             if (ctx->vmm_arenas[i].key == cols->base) {
-                for (auto &r : ctx->vmm_arenas[i].ranges) { if (r.vmm) vmm_release(r.p, r.bytes); else (void)hipFree(r.p); }
-                ctx->vmm_arenas.erase(ctx->vmm_arenas.begin() + (long)i);
+                if (ctx->arena_cache_on && ctx->vmm_arenas[i].cols.bytes <= ctx->arena_cache_max_bytes) {
+                    // keep the placement: the next arena of this shape takes it over (freed memory would be handed out again
+                    // in some other combination, and the search would start over)
+                    ctx->vmm_arenas[i].stamp = ++ctx->arena_stamp;
+                    ctx->arena_cache.push_back(std::move(ctx->vmm_arenas[i]));
+                    ctx->vmm_arenas.erase(ctx->vmm_arenas.begin() + (long)i);
+                    cache_trim(ctx, ctx->arena_cache_max_bytes);
+                } else {
+                    release_ranges(ctx->vmm_arenas[i].ranges);
+                    ctx->vmm_arenas.erase(ctx->vmm_arenas.begin() + (long)i);
+                }
                 vmm = true;
                 break;
             }

@@ -62,8 +62,26 @@ struct aesw_ctx {
     int arena_unit = 2;        // what a candidate is: 0 = the whole set of columns in one range, 1 = one column (greedy, largest first),
                                // 2 = whole sets first, columns if no set candidate runs the pattern as fast as its fill (default)
     struct ArenaRange { void *p; size_t bytes; bool vmm; };  // vmm: built with the virtual-memory API (freed by unmap), else hipMalloc
-    struct ArenaRec { void *key; std::vector<ArenaRange> ranges; };
+    // A probed arena: its ranges, and what it was placed for (the shape decides whether a later request may take it over)
+    struct ArenaRec {
+        void *key;
+        std::vector<ArenaRange> ranges;
+        uint64_t n = 0;
+        int layout = 0, with_key_slab = 0, with_ct = 0;
+        uint32_t xcd = 0;          // the "xcd_remap" the store pattern was probed with
+        aesw_columns cols = {};    // the column pointers and probe results handed to the caller
+        uint64_t stamp = 0;        // when it was freed (cache order)
+    };
     std::vector<ArenaRec> vmm_arenas;  // arenas built with the virtual-memory API (one range per column; freed by unmap, not hipFree)
+    // Placement cache: a probed arena that is freed keeps its backing (physical placement is what the search paid for); the next
+    // aesw_columns_alloc of the same shape takes it over without a search.  Bounded by arena_cache_max_bytes, oldest out first;
+    // flushed when a search runs short of memory, by option "arena_cache" = 0 and by aesw_destroy.
+    std::vector<ArenaRec> arena_cache;
+    int arena_cache_on = 1;
+    uint64_t arena_cache_max_bytes = (uint64_t)64 << 30;
+    uint64_t arena_stamp = 0;
+    uint64_t arena_cache_hits = 0;
+    int64_t arena_probe_budget_ms = 3000;  // a search stops building candidates once it has run this long (0 = no limit); it always keeps the best so far
 #ifdef AESW_TRACE
     uint64_t *trace = nullptr;
 #endif
@@ -107,5 +125,7 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+void aesw_arena_cache_trim(aesw_ctx *ctx, uint64_t keep_bytes);  // aesw_arena.cpp: release cached arenas, oldest first, until keep_bytes stay
 
 inline bool aesw_valid_layout(int l) { return l == AESW_LAYOUT_DENSE || l == AESW_LAYOUT_PACKED || l == AESW_LAYOUT_VALUES; }

@@ -282,8 +282,19 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
  * caller's blocking streams: allocate outside timed or latency-critical sections), never lets the held candidates take
  * the device's last 16 GB, and takes 0.2 - 1.5 s for a 2^20-block set (up to 5 s on a GPU where no candidate is fast).  Every column
  * starts on a 2 MiB boundary; with probing `base` is only the handle the arena is freed by and `bytes` the sum of its ranges.
- * Unused members are NULL.  aesw_columns_free releases the arena and clears the struct; cols must come from
- * aesw_columns_alloc on the same context. */
+ * "arena_probe_budget_ms" (default 3000, 0 = no limit) bounds a search: once it has run that long it builds no further
+ * candidate and keeps the best one it has (every unit still gets its first candidate).
+ * Placement cache ("arena_cache", default 1).  What the search pays for is a physical placement, and freed memory comes back
+ * from the driver in some other combination, so aesw_columns_free of a PROBED arena keeps its ranges mapped inside the
+ * context, and the next aesw_columns_alloc with the same n, layout, with_key_slab, with_ct (and "xcd_remap") takes them over:
+ * no candidate is built or timed (candidates = 0; probe_us / fill_us are the earlier search's), the call returns in
+ * microseconds and the kernel runs at the rate measured then.  This is the shape of the consumer: one synthesize() per proof,
+ * three passes per proof (keygen_vk, keygen_pk, create_proof: benches/aes128.rs:80-107), batch after batch of one size.
+ * At most "arena_cache_max_mb" (default 65536) stay cached, oldest out first; everything cached is released when a search
+ * for a new shape finds less free memory than twice its size + 16 GB, by aesw_set_option("arena_cache", 0) and by
+ * aesw_destroy.  Arenas allocated with probing off are plain hipMalloc / hipFree and never cached.
+ * Unused members are NULL.  aesw_columns_free releases the arena (or hands it to the cache) and clears the struct; cols must
+ * come from aesw_columns_alloc on the same context. */
 typedef struct aesw_columns {
     uint8_t *base;  /* the allocation (arena_probe 0) / the handle of the arena */
     uint64_t bytes; /* device memory held */
@@ -292,7 +303,7 @@ typedef struct aesw_columns {
     uint8_t *z;
     uint8_t *ct;    /* n * 16, or NULL */
     aesw_key_slab key; /* n key slabs, or NULLs */
-    uint32_t candidates; /* candidate backings built and timed in all, over every unit (0: probing off) */
+    uint32_t candidates; /* candidate backings built and timed in all, over every unit (0: probing off, or taken from the placement cache) */
     uint32_t chosen;     /* reserved (0) */
     float probe_us;      /* store-pattern emulation over the set as placed, microseconds per pass */
     float fill_us;       /* a linear fill of the same bytes */
@@ -417,10 +428,13 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * striding kernel), "arena_align_log2" (column alignment of aesw_columns_alloc, 0 = auto), "arena_probe" (candidate backings
  * aesw_columns_alloc measures per unit, -1 = auto: 8 for batches of at least 2^16 blocks, 0 = none: one hipMalloc), "arena_unit" (what a candidate
  * backs: 0 = the whole set of columns in one range; 1 = one column, placed greedily, largest first; 2 = whole sets first, then
- * columns if no whole-set candidate ran the pattern as fast as its fill: the default).
+ * columns if no whole-set candidate ran the pattern as fast as its fill: the default), "arena_cache" (1 = a freed probed arena keeps its
+ * backing for the next aesw_columns_alloc of the same shape: the default; 0 = off, and releases what is cached), "arena_cache_max_mb"
+ * (bytes the cache may hold, default 65536), "arena_probe_budget_ms" (wall-time bound of one placement search, default 3000, 0 = none).
  * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
  * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied), and "effective_copy_threads", and the
- * read-only statistics "key_reader_waits" (reader events schedules have waited on), "key_slots_allocated", "key_slots_pinned".
+ * read-only statistics "key_reader_waits" (reader events schedules have waited on), "key_slots_allocated", "key_slots_pinned",
+ * "arena_cache_hits", "arena_cached_bytes".
  * Unknown -> INVALID_ARG */
 int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value);
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value);

@@ -10,6 +10,8 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: timing bounds on a real MI355X (run with -m perf; NOT part of -m gpu, so a noisy lease "
+                                       "cannot redden the parity suite; skipped without a GPU)")
 
 
 @pytest.fixture(scope="session")

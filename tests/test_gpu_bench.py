@@ -30,6 +30,14 @@ def test_bench_single_gpu_line(pkg):
     assert d["config"]["columns"].startswith("one probed arena") and len(d["config"]["arena_probe"]) == d["config"]["output_ring_sets"]
     for a in d["config"]["arena_probe"]:
         assert a["candidates"] >= 1 and a["probe_us"] > 0 and a["fill_us"] > 0
+    # the line certifies itself: a sample of what the timed graph wrote, compared with the oracle (BASELINE.md "parity gate")
+    g = d["parity_gate"]
+    assert g["mismatches"] == 0 and g["blocks"] >= 3500 and g["sets_checked"] == d["config"]["output_ring_sets"] and "error" not in d
+    assert g["columns"] == ["kx", "ky", "kz", "w", "x", "y", "z"]
+    assert d["config"]["arena_setup_s"] > 0
+    hp = d["extra"]["headline_plain_tensors"]
+    assert "error" not in hp and hp["parity_gate"]["mismatches"] == 0 and 0.05 < hp["frac"] < 1.0
+    assert "NOT halo2" in d["extra"]["host_synthesize"]["what"]
     ex = d["extra"]
     for k in ("pcie_inclusive", "c4", "fr_columns_to_host", "c1_packed", "c1_packed_2p20", "c1_values", "c2_dense", "host_synthesize", "expand_fr",
               "key_schedule"):
@@ -47,6 +55,7 @@ def test_bench_two_ranks_on_one_gpu_rehearses_the_multi_gpu_tail(pkg):
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT), env=env)
     d = _line(out)
     assert d["n_gpus"] == 2 and "error" not in d
+    assert d["parity_gate"]["mismatches"] == 0 and d["parity_gate"]["ranks_with_mismatches"] == 0 and d["parity_gate"]["blocks_all_ranks"] >= 7000
     assert "error" not in d["gather"] and d["gather"]["path"].startswith("torch.distributed point-to-point")
     assert "error" not in d["c3"] and d["c3"]["blocks_total"] == 2 << 15
     c4 = d["c4"]

@@ -59,6 +59,8 @@ def test_probed_arena_holds_a_byte_exact_witness(ctx, pkg, oracle):
     e = oracle.encrypt_witness(pt, keys, layout=ol.PACKED)
     k = oracle.key_schedule_witness(keys, layout=ol.PACKED)
     dpt, dkeys = torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda()
+    ctx.set_option("arena_cache", 0)  # this test is about the SEARCH: every allocation below must run one (round 4's placement cache
+    # would hand the freed arena of the same shape straight back; tests/test_gpu_round4.py covers that)
     for probe in (-1, 2, 1):
         ctx.set_option("arena_probe", probe)
         w = ctx.alloc_columns(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True)
@@ -88,6 +90,7 @@ def test_probed_arena_holds_a_byte_exact_witness(ctx, pkg, oracle):
     ctx.free_columns(w)
     ctx.set_option("arena_unit", 2)
     ctx.set_option("arena_probe", -1)
+    ctx.set_option("arena_cache", 1)
 
 
 def test_every_settable_option_reads_back(pkg):
@@ -97,7 +100,8 @@ def test_every_settable_option_reads_back(pkg):
     c = pkg.Context(0)
     for name, value in (("waves_shared", 2), ("waves_pbk", 3), ("store_mode", 1), ("key_store_mode", 2), ("fr_store_mode", 0),
                         ("fr_geometry", 2), ("grid_cap", 512), ("xcd_remap", 0), ("xcd_remap", 64), ("lds_pad", 4096), ("arena_align_log2", 16), ("arena_probe", 3), ("arena_unit", 1),
-                        ("chunk_blocks", 4096), ("key_slots", 7), ("batch_streams", 5), ("copy_threads", 2)):
+                        ("chunk_blocks", 4096), ("key_slots", 7), ("batch_streams", 5), ("copy_threads", 2),
+                        ("arena_cache", 0), ("arena_cache_max_mb", 1024), ("arena_probe_budget_ms", 250)):
         c.set_option(name, value)
         assert c.get_option(name) == value, name
     c.set_option("force_table_path", 1)
@@ -118,7 +122,7 @@ def test_every_settable_option_reads_back(pkg):
 def test_probed_arena_2p22_blocks_per_block_keys_columns_beyond_4_gib(pkg, oracle):
     """2^22 blocks with per-block keys into ONE probed arena: 16.7 GB, the x column alone 5.7 GB, so every offset past 2^32
     and the arena's bookkeeping of several multi-GB candidates are exercised.  8 192 blocks sampled over the whole range
-    (first and last included) equal the oracle in all eight columns; the launch runs at the rate the arena measured."""
+    (first and last included) equal the oracle in all eight columns; the launch's time is printed next to the arena's probe (bound: tests/test_perf.py)."""
     import torch
     n = 1 << 22
     free, _ = torch.cuda.mem_get_info()
@@ -139,7 +143,7 @@ def test_probed_arena_2p22_blocks_per_block_keys_columns_beyond_4_gib(pkg, oracl
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3
-    assert us < 2.0 * info["probe_us"], (us, info)  # sanity only: a launch costs about what the probe's emulation of it cost
+    print("launch %.1f us, probe %.1f us, fill %.1f us" % (us, info["probe_us"], info["fill_us"]))  # the bound on this ratio: tests/test_perf.py
     sample = np.unique(np.concatenate([[0, n - 1], np.random.default_rng(22).integers(0, n, 8190)]))
     ds = torch.from_numpy(sample).cuda()
     pt, keys = dpt[ds].cpu().numpy(), dkeys[ds].cpu().numpy()
@@ -426,5 +430,5 @@ def test_batches_from_plain_c(pkg, tmp_path):
     out = subprocess.run([str(exe), "15", "12"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout
     ratio = float(re.search(r"three streams / one stream = ([0-9.]+)", out.stdout).group(1))
-    assert ratio < 1.10, out.stdout
+    print("three streams / one stream = %.3f" % ratio)  # reported, not asserted here: the bound lives in tests/test_perf.py (-m perf)
 
