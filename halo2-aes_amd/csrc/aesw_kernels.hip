@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(256) assemble_fr_oneshot_kernel(const Assemble
     uint64_t row;
     uint32_t v = 0;
     if (seg == 0) {  // head: key rows of set 0
-        if (r >= base) return;
+        if (r >= base || r >= rows) return;  // (a circuit of fewer than 400 rows clips the key slab: K <= 8, found by round 4's K = 7 test)
         row = r;
         const uint8_t *kc = c == 0 ? a.kx : c == 1 ? a.ky : a.kz;
         if (kc) {
@@ -1067,22 +1067,23 @@ hipError_t launch_assemble(const AssembleParams &p0, bool as_fr, int nt, hipStre
         p.cap0 = rows >= 1760 ? (rows - 1760) / AES_ROWS : 0;
         p.capn = rows / AES_ROWS;
     }
-    if (as_fr && p.geometry == 1 && p.col_count > 0) {
+    const int choice = assemble_kernel_choice(as_fr, p.geometry, p.k, p.col_count);
+    if (choice == 1) {
         const uint64_t rows = (uint64_t)1 << p.k;
         const uint64_t segs = 1 + (rows + AES_ROWS - 1) / AES_ROWS;  // head + blocks (+ the tail, clipped in the kernel)
-        if (segs > 65535 || p.col_count > 65535) return hipErrorInvalidValue;
         const dim3 grid((AES_ROWS * 2 + 255) / 256, (unsigned)segs, p.col_count);
         if (nt == 2) hipLaunchKernelGGL((assemble_fr_oneshot_kernel<2>), grid, dim3(256), 0, s, p);
         else if (nt == 1) hipLaunchKernelGGL((assemble_fr_oneshot_kernel<1>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((assemble_fr_oneshot_kernel<0>), grid, dim3(256), 0, s, p);
         return hipGetLastError();
     }
-    if (as_fr && p.geometry >= 2 && p.col_count > 0 && p.k >= 8 && p.k <= 30 && p.col_count <= 65535) {
+    if (choice == 2) {
         if (nt == 2) launch_assemble_aligned<2>(p.geometry, p.k, p.col_count, s, p);
         else if (nt == 1) launch_assemble_aligned<1>(p.geometry, p.k, p.col_count, s, p);
         else launch_assemble_aligned<0>(p.geometry, p.k, p.col_count, s, p);
         return hipGetLastError();
     }
+    // the striding kernel: any K, any column count (also where geometry 1's segment grid or the aligned forms do not apply)
     const uint64_t cells = (uint64_t)p.col_count << p.k;
     uint64_t blocks = ((as_fr ? cells * 2 : cells / 4) + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

@@ -431,6 +431,21 @@ inline void key_assigned_mask(int col, uint8_t mask[KEY_ROWS]) {
     }
 }
 
+// Which kernel writes the Fr form of aesw_assemble_advice_* for a K / column count under option "assemble_geometry": 0 = the
+// striding kernel (any shape), 1 = one-shot workgroups on a (chunk, segment, column) grid -- needs 1 + ceil(2^K / 1360) <= 65535
+// segments in grid.y --, 2 = one-shot workgroups on aligned chunks (geometries 2 / 3 / 4: 8 <= K <= 30).  A geometry that cannot
+// cover the shape falls back to the striding kernel: an option never turns a valid call into an error.
+inline int assemble_kernel_choice(bool as_fr, int geometry, uint32_t k, uint32_t col_count) {
+    if (!as_fr || col_count == 0) return 0;
+    if (geometry == 1) {
+        const uint64_t rows = (uint64_t)1 << k;
+        const uint64_t segs = 1 + (rows + AES_ROWS - 1) / AES_ROWS;
+        return segs <= 65535 && col_count <= 65535 ? 1 : 0;
+    }
+    if (geometry >= 2) return k >= 8 && k <= 30 && col_count <= 65535 ? 2 : 0;
+    return 0;
+}
+
 // Closed forms of the dense-row -> packed-index maps (the prefix counts of encrypt_assigned_mask / key_assigned_mask
 // above; -1 = the row is never assigned in that column).  The assemble kernels use these instead of a table so that a
 // cell is a chain of two loads (slab byte -> Fr LUT), not three; tests/test_lane_model.py checks them row by row against

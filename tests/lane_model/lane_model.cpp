@@ -205,6 +205,10 @@ extern "C" int lane_model_packed_index(int key, int col, int row) {
     return key ? packed_index_key(col, row) : packed_index_enc(col, row);
 }
 
+extern "C" int lane_model_assemble_kernel_choice(int as_fr, int geometry, uint32_t k, uint32_t col_count) {
+    return assemble_kernel_choice(as_fr != 0, geometry, k, col_count);
+}
+
 // window geometry, for the tests
 extern "C" void lane_model_window(int layout, int col, int out[6]) {
     auto fill = [&](auto w) {

@@ -359,3 +359,89 @@ def test_placement_cache_hands_a_freed_arena_back_without_a_search(pkg, oracle):
     _same(w5, e, "xyz", "launch into a budget-bounded arena")
     c.free_columns(w5)
     c.close()
+
+
+# ---- byte -> Fr cells, every cell ------------------------------------------------
+
+FR_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001  # bn256::Fr (halo2curves 0.6.1, Cargo.lock:779-781)
+
+
+def _fr_lut():
+    """Fp::from(u64) for a byte (src/utils.rs:23, src/aes128.rs:187): Montgomery form v * 2^256 mod r, 32 bytes little-endian."""
+    return np.stack([np.frombuffer(((v << 256) % FR_MOD).to_bytes(32, "little"), np.uint8) for v in range(256)])
+
+
+@pytest.mark.parametrize("n_cells", [1, 255, 4097, (1 << 20) + 37])
+def test_expand_fr_every_cell_in_every_geometry_and_store_flavour(pkg, n_cells):
+    """aesw_expand_fr_device against the host LUT, EVERY cell, for the three geometries ("fr_geometry": striding workgroups with
+    the LUT in LDS, one-shot 4 KiB, one-shot 16 KiB) x the three store flavours ("fr_store_mode"), at sizes of one cell, one
+    short of a workgroup, one past a 4 KiB multiple, and ten workgroups and more with a ragged tail; bytes behind the last cell
+    stay untouched."""
+    import torch
+    c = pkg.Context(0)
+    lut = _fr_lut()
+    rng = np.random.default_rng(n_cells)
+    cells = rng.integers(0, 256, n_cells, dtype=np.uint8)
+    cells[: min(n_cells, 256)] = np.arange(min(n_cells, 256), dtype=np.uint8)  # every byte value where there is room
+    expect = lut[cells]
+    dcells = torch.from_numpy(cells).cuda()
+    guard = 4096
+    for geo in (0, 1, 2):
+        for mode in (0, 1, 2):
+            c.set_option("fr_geometry", geo)
+            c.set_option("fr_store_mode", mode)
+            buf = torch.full((n_cells * 32 + guard,), 0xCC, dtype=torch.uint8, device="cuda")
+            out = buf[: n_cells * 32].view(n_cells, 32)
+            c.expand_fr(dcells, out)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy()
+            assert np.array_equal(got[: n_cells * 32].reshape(n_cells, 32), expect), (geo, mode)
+            assert (got[n_cells * 32:] == 0xCC).all(), (geo, mode, "wrote past the last cell")
+    assert lut[1].tobytes() == bytes.fromhex("fbffff4f1c3496ac29cd609f9576fc362e4679786fa36e662fdf079ac1770a0e")  # Fr::one() = R
+    c.close()
+
+
+def _small_k_expectation(oracle, k, n_sets, key):
+    """The advice matrix of a circuit too small for the reference to run (2^K < 1 760 rows: no block fits, and below K = 9 not
+    even the 400 key rows do): what aesw_assemble_advice_* defines there is the key slab clipped at 2^K rows, everything else
+    0 -- built here from the oracle's DENSE key slab."""
+    rows = 1 << k
+    kd = oracle.key_schedule_witness(key.reshape(1, 16), layout=ol.DENSE)
+    m = np.zeros((3 * n_sets + 1, rows), np.uint8)
+    for col, src in ((0, kd.kx), (1, kd.ky), (2, kd.kz)):
+        m[col, : min(rows, 400)] = src[: min(rows, 400)]
+    m[3 * n_sets, : min(rows, 96)] = kd.w[: min(rows, 96)]
+    return m
+
+
+@pytest.mark.parametrize("k,n_sets,spare", [(7, 2, 0), (8, 2, 0), (9, 1, 0), (11, 2, 0), (16, 3, 20)])
+def test_assemble_geometries_at_the_fallback_boundary_and_with_a_partly_filled_last_set(ctx, pkg, oracle, k, n_sets, spare):
+    """The five "assemble_geometry" forms write identical Fr columns and byte columns on both sides of K = 8 (below it the
+    aligned forms 2-4 fall back to the striding kernel, aesw_layout.h assemble_kernel_choice), at K = 11 (the smallest circuit
+    the reference's capacity rule gives a block: one, in set 1) and for K = 16, N = 3 with twenty empty block slots at the end
+    of the last set; every cell equals the restated synthesize() (K >= 11) or the clipped key slab (K < 11)."""
+    import torch
+    lut = _fr_lut()
+    cap = pkg.block_capacity(k, n_sets)
+    n = cap - spare
+    assert n >= 0 and (k != 11 or n == 1) and (k != 16 or n == 46 + 48 + 48 - 20)
+    rng = np.random.default_rng(1000 + k)
+    key = rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = rng.integers(0, 256, (max(n, 1), 16), dtype=np.uint8)
+    kw = ctx.schedule_key(torch.from_numpy(key).cuda(), layout=pkg.LAYOUT_PACKED, key_slab=True)
+    wit = ctx.encrypt_witness(torch.from_numpy(pts).cuda(), None, layout=pkg.LAYOUT_PACKED)
+    if k >= 11:
+        with oracle.circuit(k, n_sets, key, pts[:n], record_copies=False) as circ:
+            assert circ.status == 0
+            expect = np.stack([circ.advice(col) for col in range(3 * n_sets + 1)])
+    else:
+        expect = _small_k_expectation(oracle, k, n_sets, key)
+    try:
+        for geo in range(5):
+            ctx.set_option("assemble_geometry", geo)
+            fr = ctx.assemble_advice(k, n_sets, wit, kw, n, layout=pkg.LAYOUT_PACKED, as_fr=True).cpu().numpy()
+            by = ctx.assemble_advice(k, n_sets, wit, kw, n, layout=pkg.LAYOUT_PACKED, as_fr=False).cpu().numpy()
+            assert np.array_equal(by, expect), (geo, "bytes")
+            assert np.array_equal(fr, lut[expect]), (geo, "Fr cells")
+    finally:
+        ctx.set_option("assemble_geometry", 4)

@@ -170,3 +170,18 @@ def test_flush_table_is_dealt_for_the_lds_banks(model):
         built, plain = C.c_int(), C.c_int()
         model.lane_model_flush_conflict_costs(layout, C.byref(built), C.byref(plain))
         assert 0 < built.value <= limit * plain.value, (layout, built.value, plain.value)
+
+
+def test_assemble_geometry_falls_back_to_the_striding_kernel_where_it_cannot_cover_the_grid(model):
+    """"assemble_geometry" 1 puts 1 + ceil(2^K / 1360) segments into grid.y (<= 65535), i.e. K <= 26; the entry
+    points accept K up to 30 (device) / 28 (host).  The launcher's dispatch (assemble_kernel_choice, shared source) must fall
+    back to the striding kernel (0) there instead of failing, as the aligned geometries 2-4 do outside 8 <= K <= 30."""
+    f = model.lane_model_assemble_kernel_choice
+    for k in range(2, 33):
+        segs = 1 + -(-(1 << k) // 1360)
+        assert f(1, 1, k, 16) == (1 if segs <= 65535 else 0), k
+        for geo in (2, 3, 4):
+            assert f(1, geo, k, 16) == (2 if 8 <= k <= 30 else 0), (geo, k)
+        assert f(1, 0, k, 16) == 0 and f(0, 1, k, 16) == 0 and f(0, 4, k, 16) == 0  # byte cells: always the striding kernel
+    assert f(1, 1, 26, 16) == 1 and f(1, 1, 27, 16) == 0 and f(1, 1, 28, 16) == 0
+    assert f(1, 1, 20, 65535) == 1 and f(1, 1, 20, 65536) == 0 and f(1, 4, 20, 65536) == 0 and f(1, 4, 20, 0) == 0
