@@ -110,6 +110,18 @@ bool stream_capturing(hipStream_t s) {
     return cs != hipStreamCaptureStatusNone;
 }
 
+// Both streams are being captured into the SAME graph (one forked from the other with an event, like the internal streams of
+// the batch entry point from the caller's).
+bool same_capture(hipStream_t a, hipStream_t b) {
+    hipStreamCaptureStatus sa = hipStreamCaptureStatusNone, sb = hipStreamCaptureStatusNone;
+    unsigned long long ia = 0, ib = 0;
+    if (hipStreamGetCaptureInfo(a, &sa, &ia) != hipSuccess || hipStreamGetCaptureInfo(b, &sb, &ib) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return sa == hipStreamCaptureStatusActive && sb == hipStreamCaptureStatusActive && ia == ib;
+}
+
 // While some stream of this thread is being captured (global mode), allocation calls are refused: run them relaxed.
 struct RelaxedCapture {
     hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
@@ -457,6 +469,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "batch_streams")) { if (value < 1 || value > 8) return AESW_ERR_INVALID_ARG; ctx->batch_streams = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "copy_threads")) { if (value < -1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->copy_threads = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "key_slots")) { if (value < 1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->key_ring = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "split_small")) { if (value < 0 || value > 8) return AESW_ERR_INVALID_ARG; ctx->split_small = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache")) {  // 0 also releases what is cached now
         if (value != 0 && value != 1) return AESW_ERR_INVALID_ARG;
         ctx->arena_cache_on = (int)value;
@@ -538,6 +551,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "copy_threads")) { *value = ctx->copy_threads; return AESW_OK; }
     if (!std::strcmp(name, "effective_copy_threads")) { *value = auto_copy_threads(ctx); return AESW_OK; }
     if (!std::strcmp(name, "key_slots")) { *value = ctx->key_ring; return AESW_OK; }
+    if (!std::strcmp(name, "split_small")) { *value = ctx->split_small; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache")) { *value = ctx->arena_cache_on; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache_max_mb")) { *value = (int64_t)(ctx->arena_cache_max_bytes >> 20); return AESW_OK; }
     if (!std::strcmp(name, "arena_probe_budget_ms")) { *value = ctx->arena_probe_budget_ms; return AESW_OK; }
@@ -651,6 +665,28 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
     }
     const bool kemit = ko.w || ko.kx || ko.ky || ko.kz;
     if (!d_keys && kemit) return AESW_ERR_INVALID_ARG;  // the key slab of a scheduled key comes from aesw_schedule_key*
+    if (ctx->split_small > 1 && !ctx->in_split && !per_block_keys && !kemit && n >= ((uint64_t)1 << 15) && n <= ((uint64_t)1 << 17)) {
+        // "split_small": the lone small batch as 2-3 sub-launches on the internal streams (fork / join as in the batch entry
+        // point).  Sub-ranges are multiples of 48 blocks -- whole 3-wave groups, and 48 x 1360 / 1056 / 608 are multiples of the
+        // 128-byte line, so no two sub-launches share a line of any column.
+        const uint32_t parts = (uint32_t)ctx->split_small;
+        const uint64_t per = ((n + parts - 1) / parts + 47) / 48 * 48;
+        aesw_batch b[8];
+        uint32_t cnt = 0;
+        const uint64_t sx = aesw_column_stride(layout, 0), sy = aesw_column_stride(layout, 1), sz = aesw_column_stride(layout, 2);
+        for (uint64_t lo = 0; lo < n && cnt < 8; lo += per, ++cnt) {
+            const uint64_t m = n - lo < per ? n - lo : per;
+            b[cnt] = aesw_batch{d_pt + lo * 16, d_keys, m, d_x ? d_x + lo * sx : nullptr, d_y + lo * sy, d_z + lo * sz,
+                                d_ct ? d_ct + lo * 16 : nullptr, nullptr};
+        }
+        const int keep = ctx->batch_streams;
+        ctx->batch_streams = (int)cnt;
+        ctx->in_split = true;
+        const int rc = aesw_encrypt_witness_batches_device(ctx, b, cnt, 0, layout, stream);
+        ctx->in_split = false;
+        ctx->batch_streams = keep;
+        return rc;
+    }
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -664,7 +700,11 @@ int aesw_encrypt_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_
     if (km == 2 && s != ctx->key_slots[ctx->key_cur].writer) {
         // the round keys were written on another stream: order this launch behind them
         aesw_ctx::KeySlot &sl = ctx->key_slots[ctx->key_cur];
-        if (cap) {
+        if (cap && same_capture(s, sl.writer)) {
+            // `s` was forked (with an event) from the capture on the key's own stream -- the internal streams of the batch entry
+            // point and of "split_small" are: whatever ordered the key in front of that capture orders it in front of `s` too.
+            // (Asking the key's event would be an error here: its stream is the one being captured.)
+        } else if (cap) {
             // a captured launch cannot take a dependency on work outside its graph.  If the key launch has already finished,
             // there is nothing to depend on; otherwise refuse instead of dropping the wait silently
             RelaxedCapture relaxed;
@@ -722,11 +762,14 @@ int aesw_encrypt_witness_batches_device(aesw_ctx *ctx, const aesw_batch *batches
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, s));
     for (uint32_t j = 0; j < ns; ++j) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_batch[j], ctx->ev_fork, 0));
     int rc = AESW_OK;
+    const bool outer = !ctx->in_split;
+    ctx->in_split = true;  // the launches below already sit on the internal streams: "split_small" must not deal them out again
     for (uint32_t i = 0; i < count && rc == AESW_OK; ++i) {
         const aesw_batch &b = batches[i];
         rc = aesw_encrypt_witness_device(ctx, b.d_pt, b.d_keys, per_block_keys, b.n, layout, b.d_x, b.d_y, b.d_z, b.d_ct, b.d_key_slab,
                                          ctx->s_batch[i % ns]);
     }
+    if (outer) ctx->in_split = false;
     // join, also after a failed launch: what was issued must be ordered before whatever the caller does next on `stream`
     for (uint32_t j = 0; j < ns; ++j) {
         const hipError_t e1 = hipEventRecord(ctx->ev_join[j], ctx->s_batch[j]);

@@ -89,6 +89,9 @@ struct aesw_ctx {
     int copy_threads = -1;           // host threads that move a stage from the page-locked bounce buffer into a pageable destination (-1 = auto)
     std::string last_error;
     hipStream_t s_compute = nullptr, s_copy = nullptr;
+    int split_small = 0;    // experiment of round 4 (profiles/r04_study/split_small.md): a LONE shared / scheduled-key launch of 2^15 .. 2^17 blocks
+                            // dealt as this many line-aligned sub-ranges onto the internal streams (0 / 1 = off)
+    bool in_split = false;  // re-entrancy guard of the above
     int batch_streams = 3;  // aesw_encrypt_witness_batches_device: internal streams the batches are dealt onto
     hipStream_t s_batch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -26,21 +26,21 @@ def shard_sizes(n: int, world: int) -> List[int]:
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
-_comms = {}  # (id of ctx, group) -> api.Comm
-_agreed_max = {}  # (id of ctx, group, requested bytes) -> the group-wide minimum (all ranks must cut messages alike)
 last_gather_path = None  # "aesw_gather_columns_device (RCCL)" or "torch.distributed point-to-point": what the last call used
 
 
 def _aesw_comm(ctx, group):
     """The C-ABI RCCL communicator of (ctx, group), created on first use: group rank 0 makes the unique id and the
-    existing process group carries it to the others."""
+    existing process group carries it to the others.  It is kept ON the context, next to a reference to the group (so the
+    group's id() cannot be handed to another object while the entry lives), and goes away with the context."""
     import torch
     import torch.distributed as dist
     from . import api
 
-    key = (id(ctx), id(group) if group is not None else None)
-    if key in _comms:
-        return _comms[key]
+    comms = ctx.__dict__.setdefault("_sharding_comms", {})  # id(group) -> (group, api.Comm)
+    key = id(group) if group is not None else None
+    if key in comms and comms[key][0] is group:
+        return comms[key][1]
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     uid = torch.zeros(128, dtype=torch.uint8, device="cuda:%d" % ctx.device)
     if rank == 0:
@@ -48,7 +48,7 @@ def _aesw_comm(ctx, group):
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast(uid, src=src, group=group)
     comm = api.Comm(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
-    _comms[key] = comm
+    comms[key] = (group, comm)
     return comm
 
 
@@ -66,7 +66,7 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
     without torch calls the same entry point.  Otherwise (gloo in the CPU tests) it falls back to
     torch.distributed point-to-point operations with the same index math.  A rank's range of one column travels
     as messages of at most `max_message_bytes`; sender and receiver must cut a range into the same pieces, so the
-    RCCL path uses the group-wide MINIMUM of the ranks' values (one all-reduce per distinct request, cached).
+    RCCL path uses the group-wide MINIMUM of the ranks' values (one int64 all-reduce per call).
     `force_torch=True` (or AESW_GATHER_PATH=torch in the environment) keeps the torch point-to-point path even with
     the nccl backend: the RCCL leg of the C ABI has not yet run with more than one real rank.
     """
@@ -85,12 +85,12 @@ def gather_columns(columns: Sequence, counts: Sequence[int], strides: Sequence[i
     if ctx is not None and not force_torch and dist.get_backend(group) == "nccl" and all(c.is_cuda for c in columns):
         last_gather_path = "aesw_gather_columns_device (RCCL send/recv over xGMI, C ABI)"
         comm = _aesw_comm(ctx, group)
-        akey = (id(ctx), id(group) if group is not None else None, int(max_message_bytes))
-        if akey not in _agreed_max:
-            t = torch.tensor([int(max_message_bytes)], dtype=torch.int64, device="cuda:%d" % ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-            _agreed_max[akey] = int(t.item())
-        comm.set_max_message(_agreed_max[akey])
+        # sender and receiver must cut a range into the same pieces: agree on the MINIMUM of the ranks' requests.  One int64
+        # all-reduce on EVERY call -- whether to communicate must not depend on rank-local state, or the collectives of ranks
+        # that repeat a request and ranks that change theirs stop pairing up
+        t = torch.tensor([int(max_message_bytes)], dtype=torch.int64, device="cuda:%d" % ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        comm.set_max_message(int(t.item()))
         return comm.gather_columns([c[:counts[rank] * s] for c, s in zip(columns, strides)], counts, strides, root=dst)
     last_gather_path = "torch.distributed point-to-point (%s)" % dist.get_backend(group)
     total = sum(counts)

@@ -445,3 +445,153 @@ def test_assemble_geometries_at_the_fallback_boundary_and_with_a_partly_filled_l
             assert np.array_equal(fr, lut[expect]), (geo, "Fr cells")
     finally:
         ctx.set_option("assemble_geometry", 4)
+
+
+# ---- SURVEY 8(e) / BASELINE configs[3]: the eight-rank shape of the C ABI's gather, without eight GPUs -----------------
+
+@pytest.mark.parametrize("root", [0, 5])
+def test_gather_pieces_pair_up_across_eight_ranks(pkg, tmp_path, root):
+    """VERDICT r03 next 5(a).  aesw_gather_columns_device run as EVERY one of eight ranks (one process each, one after the other,
+    on the one GPU) against the recording stand-in for librccl: ragged block counts with one rank that has nothing, a
+    max_message that cuts every non-empty range of every column into three pieces or more.  What must hold for the real
+    exchange not to hang or scramble: per peer the root's receives and the peer's sends are the SAME list of sizes in the same
+    order (RCCL pairs the k-th send to a peer with the k-th receive from it), the receives land back to back at the peer's
+    block offset of each column, nobody posts anything for the empty rank or for the root itself, every rank opens exactly one
+    group, all traffic is ncclUint8."""
+    import os
+    import subprocess
+    from pathlib import Path
+    ROOT = Path(__file__).resolve().parent.parent
+    mock_dir, lib_dir = ROOT / "tests" / "mock_rccl", ROOT / "halo2-aes_amd"
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-o", str(tmp_path / "librccl.so"), str(mock_dir / "mock_rccl.c")], check=True)
+    exe = tmp_path / "gather_driver"
+    subprocess.run(["gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I", str(ROOT / "include"), "-I", "/opt/rocm/include",
+                    str(mock_dir / "gather_driver.c"), "-o", str(exe), "-L", str(lib_dir), "-laesw", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    world, counts, strides, maxmsg = 8, [9, 4, 0, 7, 1, 12, 3, 5], [1360, 1056, 608], 200
+    offs = [sum(counts[:r]) for r in range(world)]
+    assert all(c == 0 or c * min(strides) >= 3 * maxmsg for c in counts)
+
+    def run(rank):
+        log = tmp_path / ("log_%d_%d" % (root, rank))
+        env = dict(os.environ, MOCK_RCCL_LOG=str(log), GATHER_ROOT=str(root),
+                   LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        out = subprocess.run([str(exe), str(world), str(rank), str(maxmsg)] + [str(c) for c in counts], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True, timeout=120)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stdout
+        base = {}
+        for line in out.stdout.splitlines():
+            if line.startswith("col"):
+                _, c, _, s, _, r = line.split()
+                base[int(c)] = (int(s), int(r))
+        calls = [l.split() for l in log.read_text().splitlines()]
+        assert calls[0][0] == "id" and calls[1][:3] == ["init", str(world), str(rank)] and calls[-1][0] == "destroy"
+        body = calls[2:-1]
+        assert [c[0] for c in body].count("group_start") == 1 and body[0][0] == "group_start" and body[-1][0] == "group_end"
+        assert not any("badtype" in c[0] for c in body)
+        return base, body[1:-1]
+
+    logs = {r: run(r) for r in range(world)}
+    rbase, rcalls = logs[root]
+    assert all(c[0] == "recv" for c in rcalls)  # the root's own range is a device-to-device copy, not a message
+    recv_by_peer = {p: [(int(c[2]), int(c[3])) for c in rcalls if int(c[1]) == p] for p in range(world)}
+    assert recv_by_peer[root] == [] and recv_by_peer[2] == []
+    for p in range(world):
+        base, calls = logs[p]
+        if p == root:
+            continue
+        assert all(c[0] == "send" and int(c[1]) == root for c in calls), (p, calls[:3])
+        sends = [(int(c[2]), int(c[3])) for c in calls]
+        recvs = recv_by_peer[p]
+        assert [m for _, m in sends] == [m for _, m in recvs], p                       # same sizes, same order: they pair up
+        assert sum(m for _, m in sends) == counts[p] * sum(strides)
+        assert all(0 < m <= maxmsg for _, m in sends)
+        if counts[p] == 0:
+            assert sends == [] and recvs == []
+            continue
+        # walk both lists column by column: contiguous pieces from the send base / at the peer's block offset on the root
+        i = 0
+        for c, s in enumerate(strides):
+            nbytes, o = counts[p] * s, 0
+            npieces = 0
+            while o < nbytes:
+                (sa, sm), (ra, rm) = sends[i], recvs[i]
+                assert sa == base[c][0] + o and ra == rbase[c][1] + offs[p] * s + o and sm == rm == min(maxmsg, nbytes - o), (p, c, o)
+                o += sm
+                i += 1
+                npieces += 1
+            assert npieces >= 3
+        assert i == len(sends)
+
+
+@pytest.mark.parametrize("split", [2, 3, 4])
+def test_split_small_is_byte_exact(pkg, oracle, split):
+    """Option "split_small" (round 4's experiment, off by default: profiles/r04_study/split_small.md): a lone shared- or
+    scheduled-key batch of 2^15 .. 2^17 blocks dealt as `split` sub-ranges of whole 48-block groups onto the internal streams.
+    Same bytes as one launch, ragged batch, ciphertext included, work queued before and after on the caller's stream ordered
+    around it; sizes outside the window and per-block keys are left alone."""
+    import torch
+    c = pkg.Context(0)
+    c.set_option("split_small", split)
+    assert c.get_option("split_small") == split
+    rng = np.random.default_rng(60 + split)
+    n = (1 << 15) + 1234
+    pt, key = rng.integers(0, 256, (n, 16), dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)
+    dpt, dkey = torch.from_numpy(pt).cuda(), torch.from_numpy(key).cuda()
+    e = oracle.encrypt_witness(pt, key, layout=ol.PACKED, threads=THREADS)
+    s = torch.cuda.Stream()
+    for mode in ("scheduled", "shared"):
+        out = c.alloc_witness(n, pkg.LAYOUT_PACKED, want_ct=True)
+        with torch.cuda.stream(s):
+            if mode == "scheduled":
+                c.schedule_key(dkey, key_slab=False)
+            for t in (out.x, out.y, out.z, out.ct):
+                t.fill_(0x77)                      # queued BEFORE the call on the caller's stream
+            c.encrypt_witness(dpt, None if mode == "scheduled" else dkey, out=out, want_ct=True)
+            x_after = out.x.clone()                # queued AFTER it
+        torch.cuda.synchronize()
+        _same(out, e, "xyz", "%s key, split %d" % (mode, split))
+        assert np.array_equal(out.ct.cpu().numpy(), e.ct) and np.array_equal(x_after.cpu().numpy(), e.x)
+    # outside the window (and with per-block keys) nothing is split: same results through the ordinary path
+    small = 5000
+    out = c.encrypt_witness(dpt[:small], dkey, want_ct=True)
+    keys = rng.integers(0, 256, (1 << 15, 16), dtype=np.uint8)
+    outk = c.encrypt_witness(dpt[:1 << 15], torch.from_numpy(keys).cuda(), want_ct=True)
+    torch.cuda.synchronize()
+    _same(out, oracle.encrypt_witness(pt[:small], key, layout=ol.PACKED), "xyz", "below the window")
+    _same(outk, oracle.encrypt_witness(pt[:1 << 15], keys, layout=ol.PACKED, threads=THREADS), "xyz", "per-block keys")
+    c.close()
+
+
+def test_batches_with_the_scheduled_key_capture_into_one_graph(pkg, oracle):
+    """The batch entry point (and "split_small") under capture with the SCHEDULED key: the internal streams are forked from the
+    capture on the key's own stream, so the launches on them need no dependency of their own (round 3 refused this shape:
+    "captured on a stream other than the key's").  Replays are byte-exact and keep the key they were captured with."""
+    import torch
+    c = pkg.Context(0)
+    rng = np.random.default_rng(71)
+    sizes = [3000, 1 << 15, 777, (1 << 15) + 48, 48]
+    key, key2 = rng.integers(0, 256, 16, dtype=np.uint8), rng.integers(0, 256, 16, dtype=np.uint8)
+    pts = [rng.integers(0, 256, (m, 16), dtype=np.uint8) for m in sizes]
+    outs = [c.alloc_witness(m, pkg.LAYOUT_PACKED) for m in sizes]
+    dpts = [torch.from_numpy(p).cuda() for p in pts]
+    c.set_option("split_small", 3)  # the two 2^15-block batches are dealt out once more: nested use of the same streams is excluded
+    cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        c.schedule_key(torch.from_numpy(key).cuda(), key_slab=False)
+        c.encrypt_witness_batches([(dpts[i], None, outs[i]) for i in range(len(sizes))], per_block_keys=False)  # creates the streams
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        c.encrypt_witness_batches([(dpts[i], None, outs[i]) for i in range(len(sizes))], per_block_keys=False)
+        c.encrypt_witness(dpts[1], None, out=outs[1])  # a lone launch in the window: split into three
+    c.schedule_key(torch.from_numpy(key2).cuda(), key_slab=False)  # later keys do not reach into the graph
+    for _ in range(2):
+        for o in outs:
+            for t in (o.x, o.y, o.z):
+                t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for p, o in zip(pts, outs):
+            _same(o, oracle.encrypt_witness(p, key, layout=ol.PACKED, threads=THREADS), "xyz", "%d blocks" % len(p))
+    c.close()

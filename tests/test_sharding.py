@@ -65,7 +65,9 @@ def _worker(rank, world, port, n, layout, tmp, max_msg):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,max_msg", [(2, 37, 1 << 30), (3, 5, 1 << 30), (2, 1, 1 << 30), (2, 37, 1000)])
+# world size 8 is the shape of BASELINE configs[3] (2^24 blocks over 8 GPUs): eight ranks, ragged shards (203 = 8 x 25 + 3),
+# every range cut into >= 3 messages; and five blocks over eight ranks, so that three ranks have nothing to send
+@pytest.mark.parametrize("world,n,max_msg", [(2, 37, 1 << 30), (3, 5, 1 << 30), (2, 1, 1 << 30), (2, 37, 1000), (8, 203, 5000), (8, 5, 200)])
 def test_gather_columns_gloo(pkg, tmp_path, world, n, max_msg):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -120,3 +122,22 @@ def test_gather_offsets_pure_host(pkg):
     assert lib.aesw_gather_offsets(4, counts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), C.byref(total)) == 0
     assert offs.tolist() == [0, 5, 5, 12] and total.value == 13
     assert lib.aesw_gather_offsets(0, counts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), None) == 1
+
+
+def test_shard_range_and_gather_offsets_agree(pkg):
+    """the block range a rank generates (sharding.shard_range, Python) and the place the C ABI's gather
+    puts it on the root (aesw_gather_offsets, exclusive prefix sum of the counts) are the same partition -- for BASELINE
+    configs[3] (2^24 blocks, 8 GPUs: 2^21 each) and for sizes that do not divide."""
+    import ctypes as C
+    lib = pkg.load_library()
+    sh = pkg.sharding
+    for n, world in ((1 << 24, 8), ((1 << 24) + 5, 8), (1000003, 7), (5, 8), (0, 4), (1 << 20, 1)):
+        counts = np.array(sh.shard_sizes(n, world), np.uint64)
+        offs = np.zeros(world, np.uint64)
+        total = C.c_uint64()
+        assert lib.aesw_gather_offsets(world, counts.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), C.byref(total)) == 0
+        assert total.value == n
+        for r in range(world):
+            lo, hi = sh.shard_range(n, r, world)
+            assert (int(offs[r]), int(offs[r] + counts[r])) == (lo, hi), (n, world, r)
+    assert sh.shard_sizes(1 << 24, 8) == [1 << 21] * 8
