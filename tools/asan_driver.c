@@ -184,6 +184,7 @@ int main(void) {
         const size_t sx = aesw_column_stride(AESW_LAYOUT_PACKED, 0);
         uint8_t *ref_x = malloc(na * sx), *ref_y = malloc(na * 1056), *ref_z = malloc(na * 608), *got_x = malloc(na * sx);
         CHECK(aesw_encrypt_witness(ctx, hp, hk, 1, na, AESW_LAYOUT_PACKED, ref_x, ref_y, ref_z, NULL, NULL));
+        CHECK(aesw_set_option(ctx, "arena_cache", 0));  /* every allocation of this loop must SEARCH (the same shape three times) */
         for (int unit = 0; unit < 3; ++unit) {
             CHECK(aesw_set_option(ctx, "arena_unit", unit));
             CHECK(aesw_set_option(ctx, "arena_probe", 2));
@@ -223,6 +224,73 @@ int main(void) {
             }
         }
         if (aesw_encrypt_witness_batches_device(ctx, NULL, 2, 1, AESW_LAYOUT_PACKED, NULL) != AESW_ERR_INVALID_ARG) { fprintf(stderr, "batches: NULL accepted\n"); return 1; }
+        {   /* round 4: the placement cache (free keeps the backing, the same shape takes it over, another shape searches, the
+             * size bound evicts, switching it off releases) and a search under a 1 ms budget */
+            CHECK(aesw_set_option(ctx, "arena_cache", 1));
+            CHECK(aesw_set_option(ctx, "arena_probe", 2));
+            aesw_columns a1, a2, a3;
+            int64_t v = 0;
+            CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 1, 1, &a1));
+            uint8_t *first_x = a1.x;
+            if (a1.candidates == 0) { fprintf(stderr, "cache: first allocation did not search\n"); return 1; }
+            CHECK(aesw_columns_free(ctx, &a1));
+            CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 1, 1, &a2));
+            if (a2.candidates != 0 || a2.x != first_x) { fprintf(stderr, "cache: same shape was not handed back\n"); return 1; }
+            CHECK(aesw_encrypt_witness_device(ctx, d_p, d_kk, 1, na, AESW_LAYOUT_PACKED, a2.x, a2.y, a2.z, a2.ct, &a2.key, NULL));
+            HCHECK(hipMemcpy(got_x, a2.x, na * sx, hipMemcpyDeviceToHost));
+            if (memcmp(got_x, ref_x, na * sx) != 0) { fprintf(stderr, "cached arena: x differs\n"); return 1; }
+            CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 0, 0, &a3));  /* another shape while a2 is live */
+            if (a3.candidates == 0) { fprintf(stderr, "cache: another shape did not search\n"); return 1; }
+            CHECK(aesw_columns_free(ctx, &a2));
+            CHECK(aesw_columns_free(ctx, &a3));
+            CHECK(aesw_get_option(ctx, "arena_cached_bytes", &v));
+            if (v <= 0) { fprintf(stderr, "cache: nothing cached after two frees\n"); return 1; }
+            CHECK(aesw_set_option(ctx, "arena_cache_max_mb", 300));  /* evicts the older (larger) entry */
+            CHECK(aesw_get_option(ctx, "arena_cached_bytes", &v));
+            if (v > (int64_t)300 << 20) { fprintf(stderr, "cache: size bound not applied\n"); return 1; }
+            CHECK(aesw_set_option(ctx, "arena_cache", 0));
+            CHECK(aesw_get_option(ctx, "arena_cached_bytes", &v));
+            if (v != 0) { fprintf(stderr, "cache: not released\n"); return 1; }
+            CHECK(aesw_set_option(ctx, "arena_probe_budget_ms", 1));
+            CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 1, 0, &a1));
+            if (a1.candidates != 1) { fprintf(stderr, "budget: %u candidates\n", a1.candidates); return 1; }
+            CHECK(aesw_columns_free(ctx, &a1));
+            CHECK(aesw_set_option(ctx, "arena_probe_budget_ms", 3000));
+            CHECK(aesw_set_option(ctx, "arena_cache", 1));
+            CHECK(aesw_set_option(ctx, "arena_cache_max_mb", 65536));
+            CHECK(aesw_set_option(ctx, "arena_probe", -1));
+            CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 0, 0, &a1));  /* left in the cache for aesw_destroy to release */
+            CHECK(aesw_columns_free(ctx, &a1));
+        }
+        {   /* round 4: the scheduled key's slot ring.  Twenty reader streams (more than a slot tracks: folding), re-schedules
+             * on rings of 1, 2 and 4 slots, a lone launch dealt out by "split_small"; the last key's output is checked */
+            hipStream_t st[20];
+            for (int i = 0; i < 20; ++i) HCHECK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+            uint8_t *d_o2[3];
+            for (int c = 0; c < 3; ++c) HCHECK(hipMalloc((void **)&d_o2[c], na * aesw_column_stride(AESW_LAYOUT_PACKED, c)));
+            for (int ring = 1; ring <= 4; ring <<= 1) {
+                CHECK(aesw_set_option(ctx, "key_slots", ring));
+                for (int k = 0; k < 6; ++k) {
+                    CHECK(aesw_schedule_key_device(ctx, d_kk + 16 * k, AESW_LAYOUT_PACKED, NULL, st[k % 3]));
+                    for (int i = 0; i < 20; ++i)  /* every stream writes its own 64-block range */
+                        CHECK(aesw_encrypt_witness_device(ctx, d_p + (size_t)i * 64 * 16, NULL, 0, 64, AESW_LAYOUT_PACKED, d_o2[0] + (size_t)i * 64 * 1360,
+                                                          d_o2[1] + (size_t)i * 64 * 1056, d_o2[2] + (size_t)i * 64 * 608, NULL, NULL, st[i]));
+                }
+            }
+            CHECK(aesw_set_option(ctx, "split_small", 3));
+            CHECK(aesw_encrypt_witness_device(ctx, d_p, NULL, 0, na, AESW_LAYOUT_PACKED, d_o2[0], d_o2[1], d_o2[2], NULL, NULL, st[0]));
+            CHECK(aesw_set_option(ctx, "split_small", 0));
+            HCHECK(hipDeviceSynchronize());
+            CHECK(aesw_encrypt_witness(ctx, hp, hk + 16 * 5, 0, na, AESW_LAYOUT_PACKED, ref_x, ref_y, ref_z, NULL, NULL));  /* key 5 as a shared key */
+            HCHECK(hipMemcpy(got_x, d_o2[0], na * sx, hipMemcpyDeviceToHost));
+            if (memcmp(got_x, ref_x, na * sx) != 0) { fprintf(stderr, "slot ring / split_small: x differs from the last scheduled key's witness\n"); return 1; }
+            int64_t waits = 0, slots = 0;
+            CHECK(aesw_get_option(ctx, "key_reader_waits", &waits));
+            CHECK(aesw_get_option(ctx, "key_slots_allocated", &slots));
+            if (waits < 20 || slots < 4 || slots > 16) { fprintf(stderr, "slot ring: waits %lld slots %lld\n", (long long)waits, (long long)slots); return 1; }
+            for (int c = 0; c < 3; ++c) HCHECK(hipFree(d_o2[c]));
+            for (int i = 0; i < 20; ++i) HCHECK(hipStreamDestroy(st[i]));  /* readers of the current slot are still tracked: aesw_destroy frees their events */
+        }
         for (int c = 0; c < 3; ++c) HCHECK(hipFree(d_o[c]));
         HCHECK(hipFree(d_p)); HCHECK(hipFree(d_kk));
         free(hp); free(hk); free(ref_x); free(ref_y); free(ref_z); free(got_x);
