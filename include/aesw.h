@@ -189,8 +189,9 @@ int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]);
  *    synchronisation with its replays.  What remains the caller's: a graph that contains a schedule must be launched (and
  *    ordered, by the caller) before un-captured launches that are to read that key run.
  *  - A scheduled-key launch captured on a stream OTHER than the one its key was scheduled on cannot take a dependency on the
- *    key kernel: it is accepted when that kernel has already finished (synchronise first) and refused with
- *    AESW_ERR_INVALID_ARG otherwise, or when the schedule itself was captured on another stream.
+ *    key kernel: it is accepted when that kernel has already finished (synchronise first), or when its stream was forked from
+ *    the capture of the key's own stream (same graph: the internal streams of aesw_encrypt_witness_batches_device are), and
+ *    refused with AESW_ERR_INVALID_ARG otherwise.
  * All launch attributes (dynamic LDS sizes) are set by aesw_create(): launches never change function
  * attributes, so every *_device entry point may be captured into a hipGraph
  * (hipStreamBeginCapture on `stream`) and replayed. */
@@ -418,7 +419,9 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * "store_mode" (0 plain, 1 nontemporal: the default, 2 write-through sc1), "nt_stores" (0/1), "grid_cap" (max workgroups per launch,
  * 0 = one per block group), "xcd_remap" (which block groups the workgroups of one XCD take: 0 = dispatch order, 1 = one contiguous eighth of
  * the block groups per XCD (default), C >= 2 = the XCDs take turns in chunks of C groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
- * pipeline, default 2^15), "batch_streams" (internal streams of aesw_encrypt_witness_batches_device, 1 ... 8, default 3), "key_slots" (round-key slots
+ * pipeline, default 2^15), "batch_streams" (internal streams of aesw_encrypt_witness_batches_device, 1 ... 8, default 3), "split_small" (0 = off: the default; 2 ... 8: a LONE shared- or
+ * scheduled-key batch of 2^15 ... 2^17 blocks is dealt as that many sub-ranges of whole 48-block groups onto the internal streams -- an
+ * experiment of round 4 that measured 4 - 8 us SLOWER at every size, profiles/r04_study/split_small.md), "key_slots" (round-key slots
  * aesw_schedule_key* cycles through, 1 ... 64, default 4; with 1 every schedule waits for all launches reading the previous key), "copy_threads" (host threads that move a stage from the page-locked bounce buffer into a PAGEABLE destination;
  * -1 = auto: a quarter of the CPUs the process may run on, 1 ... 4; page-locked destinations receive the DMA directly and use none), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB
