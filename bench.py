@@ -84,12 +84,13 @@ class Runner:
         self.pkg, self.ctx, self.torch, self.n = pkg, ctx, torch, n
         self.arena = arena
         self.pbk, self.layout, self.key_slab = per_block_keys, layout, key_slab
+        self.key_witness = None  # the key-schedule witness of the scheduled key (shared-key workloads)
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.pt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, generator=g).cuda()
         self.keys = torch.randint(0, 256, (n, 16) if per_block_keys else (16,), dtype=torch.uint8, generator=g).cuda()
         if not per_block_keys:
             # the reference's call shape (benches/aes128.rs:50-53): schedule_key once, then encrypt() per block
-            ctx.schedule_key(self.keys, layout=layout, key_slab=True)
+            self.key_witness = ctx.schedule_key(self.keys, layout=layout, key_slab=True)
             torch.cuda.synchronize()
         per_set = sum(pkg.column_stride(layout, c) for c in range(3)) * n
         if key_slab:
@@ -302,7 +303,32 @@ def parity_gate(runner, blocks=4096, seed=SEED + 99):
             if bad:
                 mismatches += bad
                 bad_cols.append("set %d column %s: %d bytes" % (si, c, bad))
-    return {"blocks": int(idx.size), "sets_checked": min(runner.nsets, max(1, runner.graph_steps)), "columns": sorted(want),
+    device_check = None
+    if runner.layout != pkg.LAYOUT_VALUES and (runner.key_slab or runner.key_witness is not None):
+        # ... and EVERY block of every set against every constraint of the reference's circuit (aesw_check_witness_device: the
+        # MockProver::assert_satisfied of src/aes128.rs:409-418 on the device): lookups, copy constraints, the rcon gate, the
+        # plaintext and key literals.  Not a recomputation and not the oracle: the reference's own notion of a valid witness.
+        tot = {"blocks": 0, "keys": 0, "lookup_failures": 0, "copy_failures": 0, "gate_failures": 0, "input_failures": 0}
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        runner.ctx.check_witness(runner.pt[:64], runner.keys[:64] if runner.pbk else runner.keys, runner.sets[0],
+                                 runner.sets[0].key if runner.pbk else runner.key_witness, layout=runner.layout)  # builds the check table, untimed
+        e0.record()
+        reps = [runner.ctx.check_witness(runner.pt, runner.keys, s, s.key if runner.pbk else runner.key_witness, layout=runner.layout, sync=False)
+                for s in runner.sets[:min(runner.nsets, max(1, runner.graph_steps))]]
+        e1.record()
+        torch.cuda.synchronize()
+        for r in reps:
+            v = r.cpu().tolist()
+            for k_, x_ in zip(tot, v[:6]):
+                tot[k_] += int(x_)
+        device_check = dict(tot, ms_per_set=e0.elapsed_time(e1) / len(reps),
+                            satisfied=not (tot["lookup_failures"] or tot["copy_failures"] or tot["gate_failures"] or tot["input_failures"]),
+                            what="aesw_check_witness_device over every block of every set: each enabled lookup, each copy_advice() pair, the "
+                                 "rcon gate and the plaintext / key literal rows (the reference's MockProver criterion)")
+        if not device_check["satisfied"]:
+            mismatches += 1
+            bad_cols.append("device check: %r" % tot)
+    return {"blocks": int(idx.size), "sets_checked": min(runner.nsets, max(1, runner.graph_steps)), "columns": sorted(want), "device_check": device_check,
             "bytes_compared": cells, "mismatches": mismatches, "where": bad_cols[:8],
             "sample": "blocks 0..%d, %d..%d and %d random ones of the columns the timed graph wrote, every byte against oracle/aesw_oracle.c" % (
                 edge - 1, n - edge, n - 1, int(idx.size) - 2 * edge)}
@@ -814,6 +840,38 @@ def main():
             extras["host_synthesize"] = res
         except Exception as e:
             extras["host_synthesize"] = {"error": str(e)}
+        try:  # configs[3] / [4] are 2^24 blocks: generate them on this GPU in 2^20-block chunks and check EVERY block's constraints
+            nn, chunks = 1 << 20, 16
+            g24 = torch.Generator(device="cuda").manual_seed(SEED + 24)
+            w24 = ctx.alloc_columns(nn, pkg.LAYOUT_PACKED, key_slab=True) if use_arena else ctx.alloc_witness(nn, pkg.LAYOUT_PACKED, key_slab=True, n_keys=nn)
+            tot = [0] * 6
+            t_gen = t_chk = 0.0
+            for ci in range(chunks):
+                dpt24 = torch.randint(0, 256, (nn, 16), dtype=torch.uint8, device="cuda", generator=g24)
+                dk24 = torch.randint(0, 256, (nn, 16), dtype=torch.uint8, device="cuda", generator=g24)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+                ctx.encrypt_witness(dpt24, dk24, layout=pkg.LAYOUT_PACKED, out=w24, key_slab=True)
+                ev[1].record()
+                rep24 = ctx.check_witness(dpt24, dk24, w24, w24.key, layout=pkg.LAYOUT_PACKED, sync=False)
+                ev[2].record()
+                torch.cuda.synchronize()
+                t_gen += ev[0].elapsed_time(ev[1])
+                t_chk += ev[1].elapsed_time(ev[2])
+                tot = [a_ + int(b_) for a_, b_ in zip(tot, rep24.cpu().tolist()[:6])]
+            if use_arena:
+                ctx.free_columns(w24)
+            del w24
+            extras["device_check_2p24"] = {
+                "blocks": tot[0], "keys": tot[1], "lookup_failures": tot[2], "copy_failures": tot[3], "gate_failures": tot[4], "input_failures": tot[5],
+                "satisfied": not any(tot[2:]), "generate_ms": t_gen, "check_ms": t_chk, "check_blocks_per_s": tot[0] / (t_chk * 1e-3),
+                "check_read_GBps": tot[0] * BYTES_PBK / (t_chk * 1e-3) / 1e9,
+                "note": "2^24 blocks with per-block keys (the size of BASELINE configs[3] / [4]) generated in 16 launches of 2^20 and every block's "
+                        "1 760 lookup rows, 2 592 copies, gate and literal rows checked on the device (aesw_check_witness_device)"}
+            if not extras["device_check_2p24"]["satisfied"]:
+                line["error"] = "device check failed over 2^24 blocks"
+        except Exception as e:
+            extras["device_check_2p24"] = {"error": str(e)}
         try:  # byte cells -> 32-byte Fr cells
             cells = torch.randint(0, 256, (1 << 26,), dtype=torch.uint8, device="cuda")
             out = torch.empty((1 << 26, 32), dtype=torch.uint8, device="cuda")

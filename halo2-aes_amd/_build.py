@@ -67,7 +67,7 @@ def build_host(force: bool = False) -> Path:
 
 def build_product(force: bool = False) -> Path:
     srcs = [CSRC / "aesw_kernels.hip", CSRC / "aesw_api.cpp", CSRC / "aesw_arena.cpp", CSRC / "aesw_comm.cpp"]
-    deps = srcs + [CSRC / "aesw_lane.h", CSRC / "aesw_layout.h", CSRC / "aesw_internal.h", CSRC / "aesw_ctx.h", ROOT / "include" / "aesw.h"]
+    deps = srcs + [CSRC / "aesw_lane.h", CSRC / "aesw_layout.h", CSRC / "aesw_check.h", CSRC / "aesw_internal.h", CSRC / "aesw_ctx.h", ROOT / "include" / "aesw.h"]
     if not force and _newer(LIB, deps):
         return LIB
     # several ranks may get here at once (torchrun): serialise on a lock file, build under a

@@ -60,6 +60,12 @@ class Batch(C.Structure):
                 ("d_z", C.c_void_p), ("d_ct", C.c_void_p), ("d_key_slab", C.POINTER(KeySlab))]
 
 
+class CheckReport(C.Structure):
+    """aesw_check_report: what aesw_check_witness_device found."""
+    _fields_ = [("blocks", C.c_uint64), ("keys", C.c_uint64), ("lookup_failures", C.c_uint64), ("copy_failures", C.c_uint64),
+                ("gate_failures", C.c_uint64), ("input_failures", C.c_uint64), ("first", C.c_uint64)]
+
+
 class _DevView:
     """A raw device range as a __cuda_array_interface__ object, so torch can wrap it without owning it."""
 
@@ -95,6 +101,7 @@ SYMBOLS = {
     "aesw_key_schedule_witness_device": (_I, [_P, _P, _U64, _I, _P, _P, _P, _P, _P, _P]),
     "aesw_lookup_table_device": (_I, [_P, _P, _P, _P, _P, _P]),
     "aesw_expand_fr_device": (_I, [_P, _P, _U64, _P, _P]),
+    "aesw_check_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P, _P]),
     "aesw_assemble_advice_device": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
     "aesw_columns_alloc": (_I, [_P, _U64, _I, _I, _I, C.POINTER(Columns)]),
     "aesw_columns_free": (_I, [_P, C.POINTER(Columns)]),
@@ -618,6 +625,30 @@ class Context:
         rc = self._lib.aesw_expand_fr_device(self._h, cells.data_ptr(), n, out.data_ptr(), self._stream())
         self._check(rc, "aesw_expand_fr_device")
         return out
+
+    def check_witness(self, pt, keys, witness: Witness, key_witness: KeyWitness, layout: int = K.LAYOUT_PACKED, ct=None, sync: bool = True):
+        """MockProver::assert_satisfied over a batch on the device (aesw_check_witness_device; src/aes128.rs:409-418): every
+        enabled lookup, every copy_advice() pair, the round-constant gate and the literal rows of n blocks and their key slab(s).
+        keys: None, uint8[16] or uint8[n,16] (per-block keys: key_witness then holds n key slabs).  Returns a dict (counts,
+        `satisfied`, `first` = None or (unit, is_key_slab, kind, index)) after synchronising the stream; with sync=False the
+        uint64[7] device tensor the report was written to."""
+        torch = self._torch()
+        pt = self._u8(pt, "pt")
+        n = pt.shape[0]
+        pbk = keys is not None and self._u8(keys, "keys").numel() != 16
+        ks = KeySlab(*[t.data_ptr() for t in key_witness[:4]])
+        rep = torch.empty(7, dtype=torch.int64, device=self._dev())
+        rc = self._lib.aesw_check_witness_device(
+            self._h, pt.data_ptr(), keys.data_ptr() if keys is not None else None, 1 if pbk else 0, n, layout, witness.x.data_ptr(),
+            witness.y.data_ptr(), witness.z.data_ptr(), ct.data_ptr() if ct is not None else None, C.byref(ks), rep.data_ptr(), self._stream())
+        self._check(rc, "aesw_check_witness_device")
+        if not sync:
+            return rep
+        torch.cuda.current_stream().synchronize()
+        v = [int(x) & 0xFFFFFFFFFFFFFFFF for x in rep.cpu().tolist()]
+        first = None if v[6] == 0xFFFFFFFFFFFFFFFF else (v[6] >> 20, bool((v[6] >> 19) & 1), (v[6] >> 16) & 7, v[6] & 0xFFFF)
+        return {"blocks": v[0], "keys": v[1], "lookup_failures": v[2], "copy_failures": v[3], "gate_failures": v[4], "input_failures": v[5],
+                "first": first, "satisfied": not any(v[2:6])}
 
     def assemble_advice(self, k: int, n_sets: int, witness: Witness, key_witness: KeyWitness | None, n_blocks: int,
                         layout: int = K.LAYOUT_PACKED, as_fr: bool = False, out=None):

@@ -19,6 +19,7 @@
 #include "../../include/aesw.h"
 #include "aesw_internal.h"
 #include "aesw_layout.h"
+#include "aesw_check.h"
 
 using namespace aesw;
 
@@ -293,6 +294,8 @@ void aesw_destroy(aesw_ctx *ctx) {
         for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
         for (uint8_t *c : ctx->key_chunks) (void)hipFree(c);
         for (uint32_t *t : ctx->d_ftab)
+            if (t) (void)hipFree(t);
+        for (uint32_t *t : ctx->d_chktab)
             if (t) (void)hipFree(t);
     }
     delete ctx;
@@ -843,6 +846,42 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     p.out = d_out;
     HIP_TRY(ctx, launch_assemble(p, as_fr != 0, ctx->fr_nt, reinterpret_cast<hipStream_t>(stream)));
+    return AESW_OK;
+}
+
+int aesw_check_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys, int per_block_keys, uint64_t n, int layout,
+                              const uint8_t *d_x, const uint8_t *d_y, const uint8_t *d_z, const uint8_t *d_ct, const aesw_key_slab *ks,
+                              aesw_check_report *d_report, void *stream) {
+    static_assert(sizeof(aesw_check_report) == 7 * sizeof(uint64_t), "the kernels address the report as seven u64");
+    if (!ctx || !d_report || (layout != AESW_LAYOUT_DENSE && layout != AESW_LAYOUT_PACKED)) return AESW_ERR_INVALID_ARG;
+    if (per_block_keys && n && !d_keys) return AESW_ERR_INVALID_ARG;
+    if (n && (!d_pt || !d_x || !d_y || !d_z || !ks || !ks->w || !ks->kx || !ks->ky || !ks->kz)) return AESW_ERR_INVALID_ARG;
+    if (n && (!aligned4(d_pt) || !aligned4(d_x) || !aligned4(d_y) || !aligned4(d_z) || !aligned4(ks->w) || !aligned4(ks->kx) || !aligned4(ks->ky) ||
+              !aligned4(ks->kz) || (reinterpret_cast<uintptr_t>(d_report) & 7u)))
+        return AESW_ERR_INVALID_ARG;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    const int li = layout == AESW_LAYOUT_DENSE ? 0 : 1;
+    if (!ctx->d_chktab[li]) {  // built once per context and layout (first use; not under a capture: allocate it with a call outside)
+        std::vector<uint32_t> host((size_t)CHK_WORDS);
+        build_check_table(layout, host.data());
+        RelaxedCapture relaxed;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_chktab[li]), host.size() * sizeof(uint32_t)));
+        const hipError_t e = hipMemcpy(ctx->d_chktab[li], host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(ctx->d_chktab[li]); ctx->d_chktab[li] = nullptr; return fail_hip(ctx, e, "hipMemcpy(check table)"); }
+    }
+    const CheckGeo cg = check_geo(layout);
+    CheckParams p{};
+    p.pt = d_pt; p.keys = d_keys; p.x = d_x; p.y = d_y; p.z = d_z; p.ct = d_ct;
+    if (ks) { p.kw = ks->w; p.kx = ks->kx; p.ky = ks->ky; p.kz = ks->kz; }
+    p.table = ctx->d_chktab[li];
+    p.tab768 = ctx->d_tables;
+    p.report = reinterpret_cast<uint64_t *>(d_report);
+    p.n = n;
+    p.per_block_keys = per_block_keys ? 1u : 0u;
+    p.sx = cg.sx; p.sy = cg.sy; p.sz = cg.sz; p.kxs = cg.kxs; p.kys = cg.kys; p.kzs = cg.kzs; p.bi = cg.bi;
+    p.img = (cg.bi + cg.ki + 15u) & ~15u;
+    HIP_TRY(ctx, launch_check(p, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 

@@ -70,6 +70,21 @@ struct ProbeParams {
     uint32_t xcd_mode;  // xcd_group() mode of the context
 };
 hipError_t launch_probe(const ProbeParams &p, bool fill, hipStream_t s);
+// aesw_check_witness_device (aesw_check.h): constraint satisfaction of n block slabs and their key slab(s)
+struct CheckParams {
+    const uint8_t *pt;          // n*16
+    const uint8_t *keys;        // null, 16 (one key) or n*16
+    const uint8_t *x, *y, *z;   // block columns in `layout` (DENSE or PACKED)
+    const uint8_t *ct;          // n*16 or null
+    const uint8_t *kw, *kx, *ky, *kz;  // one key slab, or n with per_block_keys
+    const uint32_t *table;      // build_check_table(layout): CHK_WORDS words
+    const uint8_t *tab768;      // sbox | mul2 | mul3
+    uint64_t *report;           // aesw_check_report as 7 x u64
+    uint64_t n;
+    uint32_t per_block_keys;
+    uint32_t sx, sy, sz, kxs, kys, kzs, bi, img;  // strides, block image bytes, bytes of one wave's image region
+};
+hipError_t launch_check(const CheckParams &p, hipStream_t s);
 hipError_t launch_expand_fr(const uint8_t *cells, uint64_t n_cells, const void *fr_lut, void *out, int store_mode, int geometry, hipStream_t s);
 
 }  // namespace aesw

@@ -23,9 +23,11 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "aesw_internal.h"
 #include "aesw_lane.h"
+#include "aesw_check.h"
 
 namespace aesw {
 
@@ -893,6 +895,201 @@ hipError_t launch_probe(const ProbeParams &p0, bool fill, hipStream_t s) {
         const uint64_t groups = (p.n + BPW - 1) / BPW;
         if (groups > 0x7fffffffull) return hipErrorInvalidValue;
         hipLaunchKernelGGL(probe_fronts_kernel, dim3((unsigned)groups), dim3(LANES), 0, s, p);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// check_kernel: MockProver::assert_satisfied over slabs (aesw_check.h).  One wave = one block at a time: its three column
+// ranges (and, with per-block keys, its key slab) are copied into the wave's LDS image with coalesced dword loads, then the
+// 64 lanes walk the row, edge and gate entries of the layout's check table (LDS, loaded once per workgroup).  Read-bound:
+// 3 992 B per block with per-block keys.  Waves stride over the blocks; nothing is written but the report.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One column range of a unit on its way from global memory into the wave's LDS image: BYTES bytes as units of VEC bytes (16 where the
+// layout's strides keep both sides 16-byte aligned, 8 for the packed kz and words_column), unit lane + 64 j in lane's j-th register.
+// load() only issues the loads; store() is called a block later, so the next unit's bytes travel while the current one is checked.
+template <int BYTES, int VEC>
+struct Staged {
+    static_assert(BYTES % VEC == 0 && (VEC == 16 || VEC == 8), "whole units");
+    static constexpr int UNITS = BYTES / VEC, N = (UNITS + LANES - 1) / LANES;
+    using V = typename std::conditional<VEC == 16, u32x4, u32x2>::type;
+    V v[N];
+    __device__ __forceinline__ void load(const uint8_t *src, uint32_t lane) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const uint32_t i = lane + LANES * j;
+            if (i < (uint32_t)UNITS) v[j] = reinterpret_cast<const V *>(src)[i];
+        }
+    }
+    __device__ __forceinline__ void store(uint8_t *dst, uint32_t lane) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const uint32_t i = lane + LANES * j;
+            if (i < (uint32_t)UNITS) reinterpret_cast<V *>(dst)[i] = v[j];
+        }
+    }
+};
+
+// The fast path's form of the check table, in LDS (one copy per workgroup): offsets of cells a layout leaves out (CHECK_NONE; only
+// on rows whose tag does not read them) point at byte 0, tags that cannot fail (no lookup, U8 range) become 0, and a row entry
+// carries the offset of its value table inside t768:  w0 = ox | oy << 16,  w1 = oz | tag << 16 | table offset << 20.
+__device__ __forceinline__ void fast_row_entry(uint32_t a, uint32_t b, uint32_t &w0, uint32_t &w1) {
+    const uint32_t tag = b >> 16;
+    const uint32_t ox = (a & 0xffffu) == CHECK_NONE ? 0u : (a & 0xffffu), oy = (a >> 16) == CHECK_NONE ? 0u : (a >> 16),
+                   oz = (b & 0xffffu) == CHECK_NONE ? 0u : (b & 0xffffu);
+    const uint32_t tg = tag < 2 ? 0u : tag;
+    w0 = ox | oy << 16;
+    w1 = oz | tg << 16 | (tg >= 3 ? (tg - 3) * 256u : 0u) << 20;
+}
+__device__ __forceinline__ void load_fast_table(uint32_t *tab, const uint32_t *t) {
+    for (uint32_t r = threadIdx.x; r < (uint32_t)(AES_ROWS + KEY_ROWS); r += blockDim.x) {
+        const uint32_t base = r < (uint32_t)AES_ROWS ? CHK_ROWS + 2 * r : CHK_KROWS + 2 * (r - AES_ROWS);
+        fast_row_entry(t[base], t[base + 1], tab[base], tab[base + 1]);
+    }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)BLOCK_COPIES; i += blockDim.x) tab[CHK_EDGES + i] = t[CHK_EDGES + i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(KEY_COPIES + WORDS_ROWS); i += blockDim.x) tab[CHK_KEDGES + i] = t[CHK_KEDGES + i];
+}
+// one lookup row, branch-free: 1 if the enabled lookup has no table row
+__device__ __forceinline__ uint32_t fast_row_bad(const uint8_t *img, const uint8_t *t768, uint32_t w0, uint32_t w1) {
+    const uint32_t x = img[w0 & 0xffffu], y = img[w0 >> 16], z = img[w1 & 0xffffu], tag = (w1 >> 16) & 7u;
+    const uint32_t lk = t768[(w1 >> 20) + x];
+    const uint32_t want = tag == 2 ? (x ^ y) : lk, got = tag == 2 ? z : y;
+    return (tag != 0) & (want != got);
+}
+template <int ROWS_AT, int NROWS, int EDGES_AT, int NEDGES>
+__device__ __forceinline__ uint32_t fast_unit_bad(const uint8_t *img, const uint8_t *t768, const uint32_t *tab, uint32_t lane) {
+    uint32_t bad = 0;
+    const uint2 *rows = reinterpret_cast<const uint2 *>(tab + ROWS_AT);
+#pragma unroll 4
+    for (uint32_t r = lane; r < (uint32_t)NROWS; r += LANES) {
+        const uint2 w = rows[r];
+        bad |= fast_row_bad(img, t768, w.x, w.y);
+    }
+#pragma unroll 4
+    for (uint32_t e = lane; e < (uint32_t)NEDGES; e += LANES) {
+        const uint32_t d = tab[EDGES_AT + e];
+        bad |= img[d & 0xffffu] != img[d >> 16];
+    }
+    return bad;
+}
+
+// Fast path per block: every lane evaluates its slice branch-free out of registers ("is anything wrong with this unit?"); only a
+// unit where some lane says yes is walked again by the exact code of aesw_check.h (the code the CPU model runs), which counts
+// and names the failures.  A satisfied witness -- the normal case -- never takes the second walk.
+// Pipeline per wave: the loads of block b + stride are issued (into registers) before block b is checked out of LDS.
+template <int LAYOUT>
+struct ChkLayout {
+    static constexpr int SX = AES_ROWS, SY = LAYOUT == DENSE ? AES_ROWS : Geo<PACKED>::YS, SZ = LAYOUT == DENSE ? AES_ROWS : Geo<PACKED>::ZS;
+    static constexpr int KXS = KEY_ROWS, KYS = LAYOUT == DENSE ? KEY_ROWS : Geo<PACKED>::KYS, KZS = LAYOUT == DENSE ? KEY_ROWS : Geo<PACKED>::KZS;
+    static constexpr int BI = SX + SY + SZ, O_KY = KXS, O_KZ = KXS + KYS, O_W = KXS + KYS + KZS, KI = O_W + WORDS_ROWS;
+    static constexpr int IMG = (BI + KI + 15) / 16 * 16;
+    static constexpr int KZV = KZS % 16 == 0 && (BI + O_KZ) % 16 == 0 ? 16 : 8, WV = (BI + O_W) % 16 == 0 ? 16 : 8;
+    static_assert(SX % 16 == 0 && SY % 16 == 0 && SZ % 16 == 0 && KXS % 16 == 0 && KYS % 16 == 0 && BI % 16 == 0, "16-byte units");
+};
+
+template <int LAYOUT>
+struct StagedKey {
+    using G = ChkLayout<LAYOUT>;
+    Staged<G::KXS, 16> kx; Staged<G::KYS, 16> ky; Staged<G::KZS, G::KZV> kz; Staged<WORDS_ROWS, G::WV> w;
+    __device__ __forceinline__ void load(const CheckParams &a, uint64_t k, uint32_t lane) {
+        kx.load(a.kx + k * G::KXS, lane); ky.load(a.ky + k * G::KYS, lane); kz.load(a.kz + k * G::KZS, lane); w.load(a.kw + k * WORDS_ROWS, lane);
+    }
+    __device__ __forceinline__ void store(uint8_t *kimg, uint32_t lane) const {
+        kx.store(kimg, lane); ky.store(kimg + G::O_KY, lane); kz.store(kimg + G::O_KZ, lane); w.store(kimg + G::O_W, lane);
+    }
+};
+
+template <int LAYOUT, bool PBK>
+__global__ void __launch_bounds__(256) check_kernel(const CheckParams a) {
+    using G = ChkLayout<LAYOUT>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t check_lds[];
+    uint32_t *tab = reinterpret_cast<uint32_t *>(check_lds);
+    uint8_t *t768 = check_lds + CHK_WORDS * 4;
+    const uint32_t wave = threadIdx.x / LANES, lane = threadIdx.x % LANES;
+    uint8_t *img = t768 + 768 + wave * G::IMG;
+    uint8_t *kimg = img + G::BI;
+    for (uint32_t i = threadIdx.x; i < 768 / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(t768)[i] = reinterpret_cast<const uint32_t *>(a.tab768)[i];
+    load_fast_table(tab, a.table);
+    __syncthreads();
+    const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / LANES), gwave = (uint64_t)blockIdx.x * (blockDim.x / LANES) + wave;
+    CheckAcc acc;
+    if (gwave == 0 && lane == 0) { a.report[0] = a.n; a.report[1] = PBK ? a.n : 1; }
+    const uint32_t ct_off = tab[CHK_ROWS + 2 * (AES_ROWS - 16 + (lane & 15)) + 1] & 0xffffu;  // lanes 0..15: z of rows 1344 + lane
+    const uint32_t w_off = tab[CHK_GATES + (lane & 15)] & 0xffffu;                              // lanes 0..15: words_column row `lane`
+    if (!PBK) {  // one key slab for the whole batch: every wave keeps a copy; the first wave of the grid checks it
+        StagedKey<LAYOUT> sk;
+        sk.load(a, 0, lane);
+        sk.store(kimg, lane);
+        wave_lds_sync();
+        if (gwave == 0) check_key(img, a.table, t768, a.keys, 0, lane, LANES, acc);
+    }
+    Staged<G::SX, 16> sx; Staged<G::SY, 16> sy; Staged<G::SZ, 16> sz;
+    StagedKey<LAYOUT> skey;
+    uint32_t lit = 0, klit = 0;  // the literal rows: plaintext, ciphertext, key bytes (lanes 0..15, one byte each)
+    auto fetch = [&](uint64_t b) {
+        sx.load(a.x + b * G::SX, lane); sy.load(a.y + b * G::SY, lane); sz.load(a.z + b * G::SZ, lane);
+        if (PBK) skey.load(a, b, lane);
+        if (lane < 16) {
+            lit = a.pt[b * 16 + lane];
+            if (a.ct) lit |= (uint32_t)a.ct[b * 16 + lane] << 8;
+            if (PBK && a.keys) klit = a.keys[b * 16 + lane];
+        }
+    };
+    if (gwave < a.n) fetch(gwave);
+    for (uint64_t b = gwave; b < a.n; b += nwaves) {
+        sx.store(img, lane); sy.store(img + G::SX, lane); sz.store(img + G::SX + G::SY, lane);
+        if (PBK) skey.store(kimg, lane);
+        const uint32_t lit_b = lit, klit_b = klit;
+        wave_lds_sync();
+        if (b + nwaves < a.n) fetch(b + nwaves);  // in flight while this block is checked
+        uint32_t bad = fast_unit_bad<CHK_ROWS, AES_ROWS, CHK_EDGES, BLOCK_COPIES>(img, t768, tab, lane);
+        if (lane < 16) {
+            bad |= img[lane] != (lit_b & 0xffu);
+            if (a.ct) bad |= img[ct_off] != (lit_b >> 8);
+        }
+        if (__ballot(bad != 0) != 0) check_block(img, a.table, t768, a.pt + b * 16, a.ct ? a.ct + b * 16 : nullptr, b, lane, LANES, acc);
+        if (PBK) {
+            uint32_t kbad = fast_unit_bad<CHK_KROWS, KEY_ROWS, CHK_KEDGES, KEY_COPIES>(img, t768, tab, lane);
+            for (uint32_t r = lane; r < (uint32_t)WORDS_ROWS; r += LANES) {
+                const uint32_t gte = tab[CHK_GATES + r];
+                kbad |= ((gte >> 24) != 0) & (img[gte & 0xffffu] != ((gte >> 16) & 0xffu));
+            }
+            if (lane < 16 && a.keys) kbad |= img[w_off] != klit_b;
+            if (__ballot(kbad != 0) != 0) check_key(img, a.table, t768, a.keys ? a.keys + b * 16 : nullptr, b, lane, LANES, acc);
+        }
+        wave_lds_sync();  // the next block overwrites the image
+    }
+    // failures are the rare case: a lane that found any adds them itself
+    if (acc.lookup) atomicAdd(reinterpret_cast<unsigned long long *>(a.report + 2), (unsigned long long)acc.lookup);
+    if (acc.copy) atomicAdd(reinterpret_cast<unsigned long long *>(a.report + 3), (unsigned long long)acc.copy);
+    if (acc.gate) atomicAdd(reinterpret_cast<unsigned long long *>(a.report + 4), (unsigned long long)acc.gate);
+    if (acc.input) atomicAdd(reinterpret_cast<unsigned long long *>(a.report + 5), (unsigned long long)acc.input);
+    if (acc.first != ~0ull) atomicMin(reinterpret_cast<unsigned long long *>(a.report + 6), (unsigned long long)acc.first);
+}
+
+hipError_t launch_check(const CheckParams &p, hipStream_t s) {
+    // the report starts as (0 blocks, 0 keys, no failures, first = none); the kernel's first wave fills in the unit counts
+    hipError_t e = hipMemsetAsync(p.report, 0, 6 * sizeof(uint64_t), s);
+    if (e == hipSuccess) e = hipMemsetAsync(p.report + 6, 0xff, sizeof(uint64_t), s);
+    if (e != hipSuccess || p.n == 0) return e;
+    const uint32_t waves = 4;
+    const bool dense = p.sy == (uint32_t)AES_ROWS;
+    const size_t lds = (size_t)CHK_WORDS * 4 + 768 + (size_t)waves * (dense ? ChkLayout<DENSE>::IMG : ChkLayout<PACKED>::IMG);  // 41 / 46 KiB
+    uint64_t groups = (p.n + waves - 1) / waves;
+    if (groups > 256 * 3) groups = 256 * 3;  // three workgroups (twelve waves) per CU, every wave strides over its share of the blocks
+    const dim3 grid((unsigned)groups), block(waves * LANES);
+    if (dense) {
+        if (p.per_block_keys) hipLaunchKernelGGL((check_kernel<DENSE, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((check_kernel<DENSE, false>), grid, block, lds, s, p);
+    } else {
+        if (p.per_block_keys) hipLaunchKernelGGL((check_kernel<PACKED, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((check_kernel<PACKED, false>), grid, block, lds, s, p);
     }
     return hipGetLastError();
 }

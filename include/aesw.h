@@ -62,7 +62,7 @@
 extern "C" {
 #endif
 
-#define AESW_VERSION 101 /* 0.1.1: + aesw_columns_alloc / _free, aesw_encrypt_witness_batches_device, aesw_batch */
+#define AESW_VERSION 102 /* 0.1.2: + aesw_check_witness_device, aesw_check_report (0.1.1: aesw_columns_alloc / _free, aesw_encrypt_witness_batches_device, aesw_batch) */
 
 #define AESW_AES_ROWS 1360u          /* src/constant.rs:114 */
 #define AESW_KEY_SCHEDULE_ROWS 1760u /* src/constant.rs:113 (capacity constant only) */
@@ -239,6 +239,36 @@ int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint6
 /* src/table.rs:18-192: the four table columns as bytes (every value < 256). */
 int aesw_lookup_table_device(aesw_ctx *ctx, uint8_t *d_t0, uint8_t *d_t1, uint8_t *d_t2,
                              uint8_t *d_t3, void *stream);
+/* MockProver::assert_satisfied for a batch where it lies (the reference's only executable correctness checks,
+ * src/aes128.rs:409-418 and src/key_schedule.rs:385-392, verify constraint SATISFACTION: every enabled lookup has a row in the
+ * table of src/table.rs:18-192, the "Equality RC" gate q * (words - rcon) holds, src/key_schedule.rs:59-64, and the two cells
+ * of every copy_advice() are equal).  Per block: its 1 360 rows against the chip enabled on each (aesw_selector_tags), its
+ * 1 952 copies (aesw_block_copy_graph; the AddRoundKey rows copy from the key slab), rows 0..15 of x against d_pt and, when
+ * d_ct is given, the last xor rows against it.  Per key slab: 400 rows, 640 copies (aesw_key_copy_graph), the round-constant
+ * gate, and words_column rows 0..15 against the key when d_keys is given.  Nothing is recomputed: a witness that satisfies
+ * all of it is one the reference's circuit accepts for these inputs.
+ * d_keys: NULL, 16 B (one key) or n * 16 with per_block_keys; d_key_slab (REQUIRED): one key slab, or n with per_block_keys.
+ * layout: DENSE or PACKED (VALUES holds no x column: AESW_ERR_INVALID_ARG).  d_report: device memory, written on `stream`
+ * (zeroed by the call); read it back after synchronising.  Read-bound, ~1.5 ms per 2^20 blocks; capturable. */
+typedef struct aesw_check_report {
+    uint64_t blocks;          /* block slabs checked */
+    uint64_t keys;            /* key slabs checked (1, or n with per-block keys) */
+    uint64_t lookup_failures; /* rows whose enabled lookup has no table row */
+    uint64_t copy_failures;   /* copy_advice() pairs whose cells differ */
+    uint64_t gate_failures;   /* q_eq_rcon rows whose words_column cell is not the round constant */
+    uint64_t input_failures;  /* plaintext / key / ciphertext literal rows that differ from the inputs given */
+    uint64_t first;           /* AESW_CHECK_NONE, or the smallest failing check: decode with the macros below */
+} aesw_check_report;
+#define AESW_CHECK_NONE UINT64_MAX
+#define AESW_CHECK_UNIT(f) ((f) >> 20)              /* block index (key index for a key slab) */
+#define AESW_CHECK_IS_KEY_SLAB(f) (((f) >> 19) & 1u)
+#define AESW_CHECK_KIND(f) (((f) >> 16) & 7u)       /* 1 lookup, 2 copy, 3 gate, 4 input */
+#define AESW_CHECK_INDEX(f) ((f) & 0xffffu)         /* slab row; for a copy the edge number in aesw_block_copy_graph / aesw_key_copy_graph */
+int aesw_check_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys, int per_block_keys,
+                              uint64_t n, int layout, const uint8_t *d_x, const uint8_t *d_y,
+                              const uint8_t *d_z, const uint8_t *d_ct, const aesw_key_slab *d_key_slab,
+                              aesw_check_report *d_report, void *stream);
+
 /* Byte cells -> bn256::Fr cells (what Fp::from(u64) builds, src/utils.rs:23,
  * src/aes128.rs:187): 32-byte little-endian Montgomery form, n_cells*32 B out. */
 int aesw_expand_fr_device(aesw_ctx *ctx, const uint8_t *d_cells, uint64_t n_cells, uint8_t *d_fr,

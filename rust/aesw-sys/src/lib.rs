@@ -11,7 +11,7 @@
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const AESW_VERSION: c_int = 101;
+pub const AESW_VERSION: c_int = 102;
 
 pub const AESW_AES_ROWS: u32 = 1360; // src/constant.rs:114
 pub const AESW_KEY_SCHEDULE_ROWS: u32 = 1760; // src/constant.rs:113
@@ -116,6 +116,33 @@ pub struct aesw_batch {
     pub d_z: *mut u8,
     pub d_ct: *mut u8,
     pub d_key_slab: *const aesw_key_slab,
+}
+
+/// Report of `aesw_check_witness_device` (device memory; copy it back after synchronising the stream).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct aesw_check_report {
+    pub blocks: u64,
+    pub keys: u64,
+    pub lookup_failures: u64,
+    pub copy_failures: u64,
+    pub gate_failures: u64,
+    pub input_failures: u64,
+    pub first: u64,
+}
+pub const AESW_CHECK_NONE: u64 = u64::MAX;
+impl aesw_check_report {
+    /// MockProver::assert_satisfied: no lookup, copy, gate or literal row failed.
+    pub fn satisfied(&self) -> bool {
+        self.lookup_failures == 0 && self.copy_failures == 0 && self.gate_failures == 0 && self.input_failures == 0
+    }
+    /// (unit, is_key_slab, kind: 1 lookup / 2 copy / 3 gate / 4 input, row or edge number) of the smallest failing check.
+    pub fn first_failure(&self) -> Option<(u64, bool, u32, u32)> {
+        if self.first == AESW_CHECK_NONE {
+            return None;
+        }
+        Some((self.first >> 20, (self.first >> 19) & 1 == 1, ((self.first >> 16) & 7) as u32, (self.first & 0xffff) as u32))
+    }
 }
 
 pub type aesw_chunk_fn = unsafe extern "C" fn(
@@ -239,6 +266,21 @@ extern "C" {
         count: u32,
         per_block_keys: c_int,
         layout: c_int,
+        stream: *mut c_void,
+    ) -> c_int;
+    pub fn aesw_check_witness_device(
+        ctx: *mut aesw_ctx,
+        d_pt: *const u8,
+        d_keys: *const u8,
+        per_block_keys: c_int,
+        n: u64,
+        layout: c_int,
+        d_x: *const u8,
+        d_y: *const u8,
+        d_z: *const u8,
+        d_ct: *const u8,
+        d_key_slab: *const aesw_key_slab,
+        d_report: *mut aesw_check_report,
         stream: *mut c_void,
     ) -> c_int;
     pub fn aesw_columns_alloc(

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../halo2-aes_amd/csrc/aesw_lane.h"
+#include "../../halo2-aes_amd/csrc/aesw_check.h"
 
 using namespace aesw;
 
@@ -203,6 +204,43 @@ extern "C" void lane_model_masks(int col, uint8_t *enc_mask, uint8_t *key_mask) 
 
 extern "C" int lane_model_packed_index(int key, int col, int row) {
     return key ? packed_index_key(col, row) : packed_index_enc(col, row);
+}
+
+// The device checker's own source (aesw_check.h) on the CPU: n units, images gathered exactly as check_kernel gathers them,
+// 64 "lanes" one after the other.  report: the seven u64 of aesw_check_report.
+extern "C" int lane_model_check(const uint8_t *tab768, int layout, const uint8_t *pt, const uint8_t *keys, int per_block_keys, uint64_t n,
+                                const uint8_t *x, const uint8_t *y, const uint8_t *z, const uint8_t *ct, const uint8_t *kw, const uint8_t *kx,
+                                const uint8_t *ky, const uint8_t *kz, uint64_t *report) {
+    if (layout != DENSE && layout != PACKED) return 1;
+    std::vector<uint32_t> t(CHK_WORDS);
+    build_check_table(layout, t.data());
+    const CheckGeo g = check_geo(layout);
+    std::vector<uint8_t> img(g.bi + g.ki);
+    CheckAcc acc;
+    auto load_key = [&](uint64_t k) {
+        uint8_t *ki = img.data() + g.bi;
+        std::memcpy(ki, kx + k * g.kxs, g.kxs);
+        std::memcpy(ki + g.kxs, ky + k * g.kys, g.kys);
+        std::memcpy(ki + g.kxs + g.kys, kz + k * g.kzs, g.kzs);
+        std::memcpy(ki + g.kxs + g.kys + g.kzs, kw + k * WORDS_ROWS, WORDS_ROWS);
+    };
+    if (!per_block_keys) {
+        load_key(0);
+        for (uint32_t lane = 0; lane < 64; ++lane) check_key(img.data(), t.data(), tab768, keys, 0, lane, 64, acc);
+    }
+    for (uint64_t b = 0; b < n; ++b) {
+        std::memcpy(img.data(), x + b * g.sx, g.sx);
+        std::memcpy(img.data() + g.sx, y + b * g.sy, g.sy);
+        std::memcpy(img.data() + g.sx + g.sy, z + b * g.sz, g.sz);
+        if (per_block_keys) load_key(b);
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+            check_block(img.data(), t.data(), tab768, pt + 16 * b, ct ? ct + 16 * b : nullptr, b, lane, 64, acc);
+            if (per_block_keys) check_key(img.data(), t.data(), tab768, keys ? keys + 16 * b : nullptr, b, lane, 64, acc);
+        }
+    }
+    report[0] = n; report[1] = per_block_keys ? n : 1;
+    report[2] = acc.lookup; report[3] = acc.copy; report[4] = acc.gate; report[5] = acc.input; report[6] = acc.first;
+    return 0;
 }
 
 extern "C" int lane_model_assemble_kernel_choice(int as_fr, int geometry, uint32_t k, uint32_t col_count) {

@@ -58,7 +58,7 @@ def test_library_is_gfx950_code(pkg):
 
 def test_version_and_strerror(pkg):
     lib = pkg.load_library()
-    assert lib.aesw_version() == 101
+    assert lib.aesw_version() == 102
     assert lib.aesw_strerror(0) == b"ok"
     assert b"AES calls too many" in lib.aesw_strerror(5)   # the reference's panic text, src/aes128.rs:161
     assert b"Keys should be scheduled" in lib.aesw_strerror(6)  # src/aes128.rs:170

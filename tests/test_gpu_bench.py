@@ -34,6 +34,10 @@ def test_bench_single_gpu_line(pkg):
     g = d["parity_gate"]
     assert g["mismatches"] == 0 and g["blocks"] >= 3500 and g["sets_checked"] == d["config"]["output_ring_sets"] and "error" not in d
     assert g["columns"] == ["kx", "ky", "kz", "w", "x", "y", "z"]
+    dc = g["device_check"]  # every block of every set against every constraint (the reference's MockProver criterion, on the device)
+    assert dc["satisfied"] and dc["blocks"] == d["config"]["output_ring_sets"] << 16 and dc["keys"] == dc["blocks"] and dc["lookup_failures"] == 0
+    d24 = d["extra"]["device_check_2p24"]
+    assert "error" not in d24 and d24["satisfied"] and d24["blocks"] == 1 << 24 and d24["keys"] == 1 << 24
     assert d["config"]["arena_setup_s"] > 0
     hp = d["extra"]["headline_plain_tensors"]
     assert "error" not in hp and hp["parity_gate"]["mismatches"] == 0 and 0.05 < hp["frac"] < 1.0

@@ -292,7 +292,24 @@ def test_bench_parity_gate_sees_one_wrong_byte(ctx, pkg, pbk):
         r.sets[0].key.kz[-3] ^= 2
     torch.cuda.synchronize()
     g2 = b.parity_gate(r, blocks=2048)
-    assert g2["mismatches"] == (3 if pbk else 2) and len(g2["where"]) == (3 if pbk else 2)
+    # the sampled comparison counts the flipped bytes; the device check over ALL blocks objects too (one more entry)
+    assert g2["mismatches"] == (3 if pbk else 2) + 1 and len(g2["where"]) == (3 if pbk else 2) + 1
+    dc = g2["device_check"]
+    assert not dc["satisfied"] and dc["lookup_failures"] + dc["copy_failures"] >= (3 if pbk else 2) and g["device_check"]["satisfied"]
+    assert g["device_check"]["blocks"] == min(r.nsets, 3) * n
+    # a flipped byte in a block the sample does NOT hold is still caught -- by the device check alone
+    r.sets[0].x[5] ^= 1
+    r.sets[1].z[-1] ^= 0x80
+    if pbk:
+        r.sets[0].key.kz[-3] ^= 2
+    torch.cuda.synchronize()
+    assert b.parity_gate(r, blocks=2048)["mismatches"] == 0
+    sampled = set(np.unique(np.concatenate([np.arange(256), np.arange(n - 256, n), np.random.default_rng(b.SEED + 99).integers(0, n, 2048 - 512)])).tolist())
+    victim = next(i for i in range(300, n) if i not in sampled)
+    r.sets[0].y[victim * 1056 + 7] ^= 4
+    torch.cuda.synchronize()
+    g3 = b.parity_gate(r, blocks=2048)
+    assert g3["mismatches"] == 1 and "device check" in g3["where"][0] and not g3["device_check"]["satisfied"]
     r.close()
 
 
@@ -594,4 +611,103 @@ def test_batches_with_the_scheduled_key_capture_into_one_graph(pkg, oracle):
         torch.cuda.synchronize()
         for p, o in zip(pts, outs):
             _same(o, oracle.encrypt_witness(p, key, layout=ol.PACKED, threads=THREADS), "xyz", "%d blocks" % len(p))
+    c.close()
+
+
+# ---- MockProver::assert_satisfied on the device (aesw_check_witness_device) ---------------------------------------------
+
+def _lane_model(pkg):
+    import ctypes as C
+    import __graft_entry__ as ge
+    L = C.CDLL(str(ge.build_lane_model()))
+    L.lane_model_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64] + [C.c_void_p] * 9
+    return L
+
+
+def _model_report(L, pkg, layout, pt, keys, pbk, cols, kcols, ct):
+    import ctypes as C
+    tab = np.concatenate(pkg.reference_tables()).astype(np.uint8)
+    rep = np.zeros(7, np.uint64)
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    keep = [np.ascontiguousarray(a) if a is not None else None for a in (pt, keys, *cols, ct, *kcols)]
+    rc = L.lane_model_check(p(tab), layout, p(keep[0]), p(keep[1]), 1 if pbk else 0, pt.shape[0], p(keep[2]), p(keep[3]), p(keep[4]), p(keep[5]),
+                            p(keep[6]), p(keep[7]), p(keep[8]), p(keep[9]), p(rep))
+    assert rc == 0
+    f = int(rep[6])
+    first = None if f == 2 ** 64 - 1 else (f >> 20, bool((f >> 19) & 1), (f >> 16) & 7, f & 0xFFFF)
+    return {"blocks": int(rep[0]), "keys": int(rep[1]), "lookup_failures": int(rep[2]), "copy_failures": int(rep[3]),
+            "gate_failures": int(rep[4]), "input_failures": int(rep[5]), "first": first, "satisfied": not any(int(v) for v in rep[2:6])}
+
+
+@pytest.mark.parametrize("layout_name", ["packed", "dense"])
+@pytest.mark.parametrize("pbk", [True, False])
+def test_device_checker_accepts_the_product_and_counts_what_the_cpu_model_counts(pkg, oracle, layout_name, pbk):
+    """aesw_check_witness_device over the product's own output: satisfied.  Then 300 random single-byte changes anywhere in the
+    seven columns, the plaintext and the ciphertext: the device report (every count and the first failure) equals the report of
+    the same source run on the CPU (tests/lane_model), which tests/test_check_model.py holds to the oracle's verifier."""
+    import torch
+    lay = pkg.LAYOUT_PACKED if layout_name == "packed" else pkg.LAYOUT_DENSE
+    c = pkg.Context(0)
+    rng = np.random.default_rng(17 + pbk)
+    n = 5000 + 13
+    pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    keys = rng.integers(0, 256, (n, 16) if pbk else 16, dtype=np.uint8)
+    dpt, dkeys = torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda()
+    if pbk:
+        w = c.encrypt_witness(dpt, dkeys, layout=lay, want_ct=True, key_slab=True)
+        kw = w.key
+    else:
+        kw = c.schedule_key(dkeys, layout=lay, key_slab=True)
+        w = c.encrypt_witness(dpt, None, layout=lay, want_ct=True)
+    rep = c.check_witness(dpt, dkeys, w, kw, layout=lay, ct=w.ct)
+    assert rep["satisfied"] and rep["first"] is None and rep["blocks"] == n and rep["keys"] == (n if pbk else 1), rep
+    assert c.check_witness(dpt, None if not pbk else dkeys, w, kw, layout=lay)["satisfied"]
+    L = _lane_model(pkg)
+    targets = [w.x, w.y, w.z, kw.w, kw.kx, kw.ky, kw.kz, dpt.view(-1), w.ct.view(-1)]
+    for _ in range(300):
+        t = targets[int(rng.integers(0, len(targets)))]
+        t[int(rng.integers(0, t.numel()))] ^= int(rng.integers(1, 256))
+    torch.cuda.synchronize()
+    got = c.check_witness(dpt, dkeys, w, kw, layout=lay, ct=w.ct)
+    host = [t.cpu().numpy() for t in (w.x, w.y, w.z)], [t.cpu().numpy() for t in (kw.w, kw.kx, kw.ky, kw.kz)]
+    exp = _model_report(L, pkg, 1 if layout_name == "packed" else 0, dpt.cpu().numpy(), keys, pbk, host[0], host[1], w.ct.cpu().numpy())
+    assert got == exp, (got, exp)
+    assert not got["satisfied"] and got["lookup_failures"] + got["copy_failures"] + got["input_failures"] >= 250
+    # arguments the entry point refuses
+    with pytest.raises(pkg.AeswError):
+        c.check_witness(dpt, dkeys, w, kw, layout=pkg.LAYOUT_VALUES)
+    c.close()
+
+
+def test_device_checker_over_the_headline_batch_and_inside_a_graph(pkg):
+    """2^20 blocks with per-block keys, the product's packed output: every one of 2^20 x (1 360 + 400 rows, 1 952 + 640 copies,
+    96 gate rows, 48 literal rows) holds; captured into a hipGraph behind the launch that produces the witness, replayed."""
+    import torch
+    c = pkg.Context(0)
+    n = 1 << 20
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dpt = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+    dkeys = torch.randint(0, 256, (n, 16), dtype=torch.uint8, device="cuda", generator=g)
+    w = c.alloc_witness(n, pkg.LAYOUT_PACKED, want_ct=True, key_slab=True, n_keys=n)
+    c.encrypt_witness(dpt, dkeys, out=w, want_ct=True, key_slab=True)
+    rep = c.check_witness(dpt, dkeys, w, w.key, ct=w.ct)   # also builds the check table outside the capture
+    assert rep["satisfied"] and rep["blocks"] == n and rep["keys"] == n, rep
+    cap = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        c.encrypt_witness(dpt, dkeys, out=w, want_ct=True, key_slab=True)
+        dev_rep = c.check_witness(dpt, dkeys, w, w.key, ct=w.ct, sync=False)
+    for t in (w.x, w.y, w.z, w.key.kz):
+        t.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    v = dev_rep.cpu().tolist()
+    assert v[0] == n and v[1] == n and v[2:6] == [0, 0, 0, 0] and v[6] == -1, v
+    print("witness launch + full check of 2^20 blocks: %.3f ms" % e0.elapsed_time(e1))
+    w.z[123456 * 608 + 17] ^= 0x40
+    rep = c.check_witness(dpt, dkeys, w, w.key, ct=w.ct)
+    assert not rep["satisfied"] and rep["first"][0] == 123456 and not rep["first"][1], rep
     c.close()

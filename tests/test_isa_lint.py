@@ -70,6 +70,8 @@ def test_every_inline_asm_store_is_padded(code_object):
     for name, ins in code_object["funcs"].items():
         if name not in code_object["meta"]:
             continue
+        if _short(code_object["demangled"][name]).startswith("check_kernel<"):
+            continue  # no inline-asm store in it: its one store (the report's unit counts, a uniform pointer) is the compiler's own, hazards included
         for i, text in enumerate(ins):
             # inline-asm stores: every sc1 store, and every store in the SGPR-base form (gstore_at emits all three flavours so)
             m = re.match(r"^global_store_dwordx([24])\b.*(\bsc1\b|, s\[\d+:\d+\])", text)

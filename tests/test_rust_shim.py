@@ -33,7 +33,7 @@ C_INT = {"int": ("int", "c_int"), "uint8_t": ("int", "u8"), "uint16_t": ("int", 
          "char": ("int", "c_char"), "void": ("void",), "float": ("float", "f32")}
 RUST_INT = {"c_int": ("int", "c_int"), "u8": ("int", "u8"), "u16": ("int", "u16"), "u32": ("int", "u32"), "u64": ("int", "u64"),
             "i32": ("int", "i32"), "i64": ("int", "i64"), "usize": ("int", "usize"), "c_char": ("int", "c_char"), "c_void": ("void",), "f32": ("float", "f32")}
-NAMED = ("aesw_ctx", "aesw_comm", "aesw_key_slab", "aesw_copy_edge", "aesw_stream_stats", "aesw_columns", "aesw_batch")
+NAMED = ("aesw_ctx", "aesw_comm", "aesw_key_slab", "aesw_copy_edge", "aesw_stream_stats", "aesw_columns", "aesw_batch", "aesw_check_report")
 CALLBACKS = ("aesw_chunk_fn", "aesw_column_fn")
 
 
@@ -254,7 +254,8 @@ def test_the_parsers_see_everything(parsed):
     assert cf["aesw_gather_columns_device"][0][4] == ("d_recv", ("ptr", True, ("ptr", False, ("int", "u8"))))
     assert cf["aesw_create"][0][2] == ("sbox", ("ptr", True, ("int", "u8")))  # const uint8_t sbox[256] decays to a pointer
     assert cf["aesw_packed_index"][0][1] == ("idx", ("ptr", False, ("int", "i32")))
-    assert set(cs) == {"aesw_key_slab", "aesw_copy_edge", "aesw_stream_stats", "aesw_columns", "aesw_batch"}
+    assert set(cs) == {"aesw_key_slab", "aesw_copy_edge", "aesw_stream_stats", "aesw_columns", "aesw_batch", "aesw_check_report"}
+    assert [n for n, _ in cs["aesw_check_report"]] == ["blocks", "keys", "lookup_failures", "copy_failures", "gate_failures", "input_failures", "first"]
     assert [n for n, _ in cs["aesw_copy_edge"]] == ["dst_space", "dst_col", "dst_row", "src_space", "src_col", "src_row"]
     assert set(cc) == {"aesw_chunk_fn", "aesw_column_fn"}
     assert ck["AESW_AES_ROWS"] == 1360 and ck["AESW_ERR_COMM"] == 9 and ck["AESW_LAYOUT_VALUES"] == 2

@@ -262,6 +262,25 @@ int main(void) {
             CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 0, 0, &a1));  /* left in the cache for aesw_destroy to release */
             CHECK(aesw_columns_free(ctx, &a1));
         }
+        {   /* round 4: aesw_check_witness_device over the product's own output (per-block keys, packed): satisfied; one byte off: not */
+            aesw_columns cc;
+            aesw_check_report *d_rep, rep;
+            CHECK(aesw_columns_alloc(ctx, na, AESW_LAYOUT_PACKED, 1, 1, &cc));
+            HCHECK(hipMalloc((void **)&d_rep, sizeof rep));
+            CHECK(aesw_encrypt_witness_device(ctx, d_p, d_kk, 1, na, AESW_LAYOUT_PACKED, cc.x, cc.y, cc.z, cc.ct, &cc.key, NULL));
+            CHECK(aesw_check_witness_device(ctx, d_p, d_kk, 1, na, AESW_LAYOUT_PACKED, cc.x, cc.y, cc.z, cc.ct, &cc.key, d_rep, NULL));
+            HCHECK(hipMemcpy(&rep, d_rep, sizeof rep, hipMemcpyDeviceToHost));
+            if (rep.blocks != na || rep.keys != na || rep.lookup_failures || rep.copy_failures || rep.gate_failures || rep.input_failures || rep.first != AESW_CHECK_NONE) {
+                fprintf(stderr, "check: the product's witness does not satisfy its constraints\n"); return 1;
+            }
+            HCHECK(hipMemset(cc.z + 5 * 608 + 20, 0xEE, 1));
+            CHECK(aesw_check_witness_device(ctx, d_p, d_kk, 1, na, AESW_LAYOUT_PACKED, cc.x, cc.y, cc.z, cc.ct, &cc.key, d_rep, NULL));
+            HCHECK(hipMemcpy(&rep, d_rep, sizeof rep, hipMemcpyDeviceToHost));
+            if (rep.first == AESW_CHECK_NONE || AESW_CHECK_UNIT(rep.first) != 5 || AESW_CHECK_IS_KEY_SLAB(rep.first)) { fprintf(stderr, "check: a changed byte went unnoticed\n"); return 1; }
+            if (aesw_check_witness_device(ctx, d_p, d_kk, 1, na, AESW_LAYOUT_VALUES, cc.x, cc.y, cc.z, NULL, &cc.key, d_rep, NULL) != AESW_ERR_INVALID_ARG) { fprintf(stderr, "check: VALUES layout accepted\n"); return 1; }
+            HCHECK(hipFree(d_rep));
+            CHECK(aesw_columns_free(ctx, &cc));
+        }
         {   /* round 4: the scheduled key's slot ring.  Twenty reader streams (more than a slot tracks: folding), re-schedules
              * on rings of 1, 2 and 4 slots, a lone launch dealt out by "split_small"; the last key's output is checked */
             hipStream_t st[20];
