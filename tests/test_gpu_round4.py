@@ -711,3 +711,18 @@ def test_device_checker_over_the_headline_batch_and_inside_a_graph(pkg):
     rep = c.check_witness(dpt, dkeys, w, w.key, ct=w.ct)
     assert not rep["satisfied"] and rep["first"][0] == 123456 and not rep["first"][1], rep
     c.close()
+
+
+def test_check_from_plain_c(pkg, tmp_path):
+    """examples/aesw_check.c: generate 2^17 blocks with per-block keys into an arena, check every constraint on the device, change
+    one byte, get the block / kind / row back -- from plain C, through include/aesw.h only."""
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "aesw_check"
+    lib_dir = root / "halo2-aes_amd"
+    subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", str(root / "include"), "-I", "/opt/rocm/include",
+                    str(root / "examples" / "aesw_check.c"), "-o", str(exe), "-L", str(lib_dir), "-laesw", "-L", "/opt/rocm/lib",
+                    "-lamdhip64", "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe), "17"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok") and "first: block %d, lookup, row 40" % (((1 << 17) + 5) // 2) in out.stdout, out.stdout

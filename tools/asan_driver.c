@@ -317,5 +317,6 @@ int main(void) {
     aesw_destroy(ctx);
     free(pt); free(keys);
     printf("asan driver: ok\n");
+    fflush(stdout);  /* a failure in the runtimes' own teardown must not swallow the verdict */
     return 0;
 }

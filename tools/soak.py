@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Soak: many byte-exact comparisons against the oracle at sizes where timing-dependent faults show
 (store-data hazards, LDS ordering), random layout / key mode / size / launch options per iteration; every third iteration
-the five assemble geometries on a random circuit shape, every fourth three launches in flight on three streams."""
+the five assemble geometries on a random circuit shape, every fourth three launches in flight on three streams.
+Round 4: a random "key_slots" ring and the arena cache on or off per context, the device checker (aesw_check_witness_device) over
+every witness next to the oracle comparison -- it must say "satisfied", and "not satisfied" after one random byte is changed --, and
+every fifth iteration a re-schedule behind two reader streams (the scenario of tools/keyrace.py) against the oracle."""
 import os
 import sys
 import time
@@ -34,6 +37,8 @@ for it in range(iters):
     if rng.integers(0, 4) == 0:
         ctx.set_option("grid_cap", int(rng.integers(1, 2048)))
     ctx.set_option("xcd_remap", int(rng.choice([0, 1, 1, 2, 7, 64, 1000, 100000])))
+    ctx.set_option("key_slots", int(rng.choice([1, 1, 2, 4, 7])))
+    ctx.set_option("arena_cache", int(rng.integers(0, 2)))
     arena = bool(rng.integers(0, 2))  # round 3: output columns in a probed arena (virtual-memory backed) or in plain tensors
     ctx.set_option("arena_probe", int(rng.integers(1, 4)))
     ctx.set_option("arena_unit", int(rng.integers(0, 3)))
@@ -68,6 +73,44 @@ for it in range(iters):
             if not np.array_equal(getattr(got.key, c).cpu().numpy(), getattr(kexp, c)):
                 print("MISMATCH key slab", c, "iter", it)
                 sys.exit(1)
+    if layout != pkg.LAYOUT_VALUES:
+        # round 4: the reference's own criterion (constraint satisfaction) over every block, on the device
+        kwit = got.key if keymode == 2 else ctx.schedule_key(torch.from_numpy(keys[0]).cuda(), layout=layout, key_slab=True)
+        dk = torch.from_numpy(kh).cuda()
+        rep = ctx.check_witness(dpt, dk, got, kwit, layout=layout, ct=got.ct)
+        if not rep["satisfied"] or rep["blocks"] != n:
+            print("DEVICE CHECK FAILED on a witness equal to the oracle's: iter %d %r" % (it, rep))
+            sys.exit(1)
+        col = [got.x, got.y, got.z][int(rng.integers(0, 3))]
+        pos = int(rng.integers(0, col.numel()))
+        col[pos] ^= int(rng.integers(1, 256))
+        rep = ctx.check_witness(dpt, dk, got, kwit, layout=layout, ct=got.ct)
+        if layout == pkg.LAYOUT_PACKED and rep["satisfied"]:
+            print("DEVICE CHECK MISSED a changed byte: iter %d position %d" % (it, pos))  # (DENSE holds never-assigned cells: a change there is legal)
+            sys.exit(1)
+    if it % 5 == 2:
+        # round 4: a long scheduled-key launch on A, a short one on B, a re-schedule on C (tools/keyrace.py) -- against the oracle
+        sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        ka, kb = torch.from_numpy(keys[3]).cuda(), torch.from_numpy(keys[4]).cuda()
+        m = min(n, 1 << 17)
+        oa, ob, oc = (ctx.alloc_witness(q, pkg.LAYOUT_PACKED, want_ct=True) for q in (m, 512, 512))
+        with torch.cuda.stream(sc):
+            ctx.schedule_key(ka, key_slab=False)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sa):
+            ctx.encrypt_witness(dpt[:m], None, out=oa, want_ct=True)
+        with torch.cuda.stream(sb):
+            ctx.encrypt_witness(dpt[:512], None, out=ob, want_ct=True)
+        with torch.cuda.stream(sc):
+            ctx.schedule_key(kb, key_slab=False)
+            ctx.encrypt_witness(dpt[:512], None, out=oc, want_ct=True)
+        torch.cuda.synchronize()
+        ea = orc.encrypt_witness(pt[:m], keys[3], layout=ol.PACKED, threads=threads)
+        ec = orc.encrypt_witness(pt[:512], keys[4], layout=ol.PACKED)
+        if not (np.array_equal(oa.z.cpu().numpy(), ea.z) and np.array_equal(oa.ct.cpu().numpy(), ea.ct) and
+                np.array_equal(ob.ct.cpu().numpy(), ea.ct[:512]) and np.array_equal(oc.ct.cpu().numpy(), ec.ct)):
+            print("MISMATCH re-schedule behind two reader streams: iter %d key_slots %d" % (it, ctx.get_option("key_slots")))
+            sys.exit(1)
     if it % 3 == 0 and pkg.block_capacity(11, 2) > 0:
         # round 3: the Fr form of assemble in its four geometries on a random circuit shape (partly filled last set), all equal,
         # and equal to the restated synthesize() through the byte -> Fr table
