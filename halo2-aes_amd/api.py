@@ -102,6 +102,7 @@ SYMBOLS = {
     "aesw_lookup_table_device": (_I, [_P, _P, _P, _P, _P, _P]),
     "aesw_expand_fr_device": (_I, [_P, _P, _U64, _P, _P]),
     "aesw_check_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P, _P]),
+    "aesw_check_witness": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), C.POINTER(CheckReport)]),
     "aesw_assemble_advice_device": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
     "aesw_columns_alloc": (_I, [_P, _U64, _I, _I, _I, C.POINTER(Columns)]),
     "aesw_columns_free": (_I, [_P, C.POINTER(Columns)]),
@@ -649,6 +650,27 @@ class Context:
         first = None if v[6] == 0xFFFFFFFFFFFFFFFF else (v[6] >> 20, bool((v[6] >> 19) & 1), (v[6] >> 16) & 7, v[6] & 0xFFFF)
         return {"blocks": v[0], "keys": v[1], "lookup_failures": v[2], "copy_failures": v[3], "gate_failures": v[4], "input_failures": v[5],
                 "first": first, "satisfied": not any(v[2:6])}
+
+    def check_witness_host(self, pt, keys, cols, key_cols, layout: int = K.LAYOUT_PACKED, ct=None):
+        """aesw_check_witness: the same check for a witness in HOST memory (numpy uint8 arrays: cols = (x, y, z), key_cols =
+        (w, kx, ky, kz)); uploaded and checked in stages of "chunk_blocks" blocks."""
+        import numpy as np
+        pt = np.ascontiguousarray(pt, np.uint8).reshape(-1, 16)
+        n = pt.shape[0]
+        keys = None if keys is None else np.ascontiguousarray(keys, np.uint8)
+        pbk = keys is not None and keys.size != 16
+        keep = [np.ascontiguousarray(a, np.uint8) for a in (*cols, *key_cols)] + ([np.ascontiguousarray(ct, np.uint8)] if ct is not None else [])
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        ks = KeySlab(*[a.ctypes.data for a in keep[3:7]])
+        rep = CheckReport()
+        rc = self._lib.aesw_check_witness(self._h, p(pt), p(keys) if keys is not None else None, 1 if pbk else 0, n, layout, p(keep[0]), p(keep[1]),
+                                          p(keep[2]), p(keep[7]) if ct is not None else None, C.byref(ks), C.byref(rep))
+        self._check(rc, "aesw_check_witness")
+        f = int(rep.first)
+        first = None if f == 0xFFFFFFFFFFFFFFFF else (f >> 20, bool((f >> 19) & 1), (f >> 16) & 7, f & 0xFFFF)
+        out = {k_: int(getattr(rep, k_)) for k_ in ("blocks", "keys", "lookup_failures", "copy_failures", "gate_failures", "input_failures")}
+        out.update(first=first, satisfied=not any(out[k_] for k_ in ("lookup_failures", "copy_failures", "gate_failures", "input_failures")))
+        return out
 
     def assemble_advice(self, k: int, n_sets: int, witness: Witness, key_witness: KeyWitness | None, n_blocks: int,
                         layout: int = K.LAYOUT_PACKED, as_fr: bool = False, out=None):

@@ -256,6 +256,12 @@ int aesw_create(aesw_ctx **out, int device, const uint8_t sbox[256], const uint8
         T(hipMalloc(reinterpret_cast<void **>(&ctx->d_ftab[l]), ft.size() * sizeof(uint32_t)), "hipMalloc(flush table)");
         if (rc == AESW_OK) T(hipMemcpy(ctx->d_ftab[l], ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(flush table)");
     }
+    for (int li = 0; li < 2 && rc == AESW_OK; ++li) {  // check tables of the DENSE / PACKED layout (aesw_check.h): 24 KiB each
+        std::vector<uint32_t> ct((size_t)CHK_WORDS);
+        build_check_table(li == 0 ? AESW_LAYOUT_DENSE : AESW_LAYOUT_PACKED, ct.data());
+        T(hipMalloc(reinterpret_cast<void **>(&ctx->d_chktab[li]), ct.size() * sizeof(uint32_t)), "hipMalloc(check table)");
+        if (rc == AESW_OK) T(hipMemcpy(ctx->d_chktab[li], ct.data(), ct.size() * sizeof(uint32_t), hipMemcpyHostToDevice), "hipMemcpy(check table)");
+    }
     if (rc == AESW_OK) { int first = -1; rc = key_new_slot(ctx, &first); if (rc == AESW_OK) ctx->key_spare.push_back(first); }  // the first chunk of round-key slots
     if (rc == AESW_OK) T(warm_launch_attributes(), "hipFuncSetAttribute(max dynamic LDS)");
     if (rc == AESW_OK) T(hipMemcpy(ctx->d_tables, host, 768, hipMemcpyHostToDevice), "hipMemcpy(tables)");
@@ -849,9 +855,19 @@ int aesw_assemble_advice_device(aesw_ctx *ctx, uint32_t k, uint32_t n_sets, uint
     return AESW_OK;
 }
 
+static int check_witness_impl(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys, int per_block_keys, uint64_t n, int layout,
+                              const uint8_t *d_x, const uint8_t *d_y, const uint8_t *d_z, const uint8_t *d_ct, const aesw_key_slab *ks,
+                              aesw_check_report *d_report, void *stream, bool skip_shared_key);
+
 int aesw_check_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys, int per_block_keys, uint64_t n, int layout,
                               const uint8_t *d_x, const uint8_t *d_y, const uint8_t *d_z, const uint8_t *d_ct, const aesw_key_slab *ks,
                               aesw_check_report *d_report, void *stream) {
+    return check_witness_impl(ctx, d_pt, d_keys, per_block_keys, n, layout, d_x, d_y, d_z, d_ct, ks, d_report, stream, false);
+}
+
+static int check_witness_impl(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t *d_keys, int per_block_keys, uint64_t n, int layout,
+                              const uint8_t *d_x, const uint8_t *d_y, const uint8_t *d_z, const uint8_t *d_ct, const aesw_key_slab *ks,
+                              aesw_check_report *d_report, void *stream, bool skip_shared_key) {
     static_assert(sizeof(aesw_check_report) == 7 * sizeof(uint64_t), "the kernels address the report as seven u64");
     if (!ctx || !d_report || (layout != AESW_LAYOUT_DENSE && layout != AESW_LAYOUT_PACKED)) return AESW_ERR_INVALID_ARG;
     if (per_block_keys && n && !d_keys) return AESW_ERR_INVALID_ARG;
@@ -861,15 +877,7 @@ int aesw_check_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t 
         return AESW_ERR_INVALID_ARG;
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
-    const int li = layout == AESW_LAYOUT_DENSE ? 0 : 1;
-    if (!ctx->d_chktab[li]) {  // built once per context and layout (first use; not under a capture: allocate it with a call outside)
-        std::vector<uint32_t> host((size_t)CHK_WORDS);
-        build_check_table(layout, host.data());
-        RelaxedCapture relaxed;
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_chktab[li]), host.size() * sizeof(uint32_t)));
-        const hipError_t e = hipMemcpy(ctx->d_chktab[li], host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(ctx->d_chktab[li]); ctx->d_chktab[li] = nullptr; return fail_hip(ctx, e, "hipMemcpy(check table)"); }
-    }
+    const int li = layout == AESW_LAYOUT_DENSE ? 0 : 1;  // the check tables were uploaded by aesw_create(): nothing is allocated here
     const CheckGeo cg = check_geo(layout);
     CheckParams p{};
     p.pt = d_pt; p.keys = d_keys; p.x = d_x; p.y = d_y; p.z = d_z; p.ct = d_ct;
@@ -879,6 +887,7 @@ int aesw_check_witness_device(aesw_ctx *ctx, const uint8_t *d_pt, const uint8_t 
     p.report = reinterpret_cast<uint64_t *>(d_report);
     p.n = n;
     p.per_block_keys = per_block_keys ? 1u : 0u;
+    p.skip_shared_key = skip_shared_key ? 1u : 0u;
     p.sx = cg.sx; p.sy = cg.sy; p.sz = cg.sz; p.kxs = cg.kxs; p.kys = cg.kys; p.kzs = cg.kzs; p.bi = cg.bi;
     p.img = (cg.bi + cg.ki + 15u) & ~15u;
     HIP_TRY(ctx, launch_check(p, reinterpret_cast<hipStream_t>(stream)));
@@ -1399,6 +1408,66 @@ int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, in
     if (ky) HIP_TRY(ctx, hipMemcpy(ky, dky.p, n * kys, hipMemcpyDeviceToHost));
     if (kz) HIP_TRY(ctx, hipMemcpy(kz, dkz.p, n * kzs, hipMemcpyDeviceToHost));
     if (rk) HIP_TRY(ctx, hipMemcpy(rk, drk.p, n * RK_BYTES, hipMemcpyDeviceToHost));
+    return AESW_OK;
+}
+
+int aesw_check_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys, uint64_t n, int layout, const uint8_t *x,
+                       const uint8_t *y, const uint8_t *z, const uint8_t *ct, const aesw_key_slab *ks, aesw_check_report *report) {
+    if (!ctx || !report || (layout != AESW_LAYOUT_DENSE && layout != AESW_LAYOUT_PACKED)) return AESW_ERR_INVALID_ARG;
+    if (per_block_keys && n && !keys) return AESW_ERR_INVALID_ARG;
+    if (n && (!pt || !x || !y || !z || !ks || !ks->w || !ks->kx || !ks->ky || !ks->kz)) return AESW_ERR_INVALID_ARG;
+    *report = aesw_check_report{0, 0, 0, 0, 0, 0, AESW_CHECK_NONE};
+    if (n == 0) return AESW_OK;
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return AESW_ERR_NO_DEVICE;
+    const CheckGeo cg = check_geo(layout);
+    const uint64_t chunk = (uint64_t)ctx->chunk_blocks < n ? (uint64_t)ctx->chunk_blocks : n;
+    const uint64_t nk = per_block_keys ? chunk : 1;
+    DevBuf dpt, dkeys, dx, dy, dz, dct, dw, dkx, dky, dkz, drep;
+    HIP_TRY(ctx, dpt.alloc(chunk * 16));
+    HIP_TRY(ctx, dkeys.alloc(nk * 16));
+    HIP_TRY(ctx, dx.alloc(chunk * cg.sx)); HIP_TRY(ctx, dy.alloc(chunk * cg.sy)); HIP_TRY(ctx, dz.alloc(chunk * cg.sz));
+    HIP_TRY(ctx, dct.alloc(chunk * 16));
+    HIP_TRY(ctx, dw.alloc(nk * WORDS_ROWS)); HIP_TRY(ctx, dkx.alloc(nk * cg.kxs)); HIP_TRY(ctx, dky.alloc(nk * cg.kys)); HIP_TRY(ctx, dkz.alloc(nk * cg.kzs));
+    HIP_TRY(ctx, drep.alloc(sizeof(aesw_check_report)));
+    const aesw_key_slab dks{dw.p, dkx.p, dky.p, dkz.p};
+    if (!per_block_keys) {  // the one key slab of the batch travels once
+        if (keys) HIP_TRY(ctx, hipMemcpy(dkeys.p, keys, 16, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dw.p, ks->w, WORDS_ROWS, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dkx.p, ks->kx, cg.kxs, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dky.p, ks->ky, cg.kys, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dkz.p, ks->kz, cg.kzs, hipMemcpyHostToDevice));
+    }
+    for (uint64_t lo = 0; lo < n; lo += chunk) {
+        const uint64_t m = n - lo < chunk ? n - lo : chunk;
+        HIP_TRY(ctx, hipMemcpy(dpt.p, pt + lo * 16, m * 16, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dx.p, x + lo * cg.sx, m * cg.sx, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dy.p, y + lo * cg.sy, m * cg.sy, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(dz.p, z + lo * cg.sz, m * cg.sz, hipMemcpyHostToDevice));
+        if (ct) HIP_TRY(ctx, hipMemcpy(dct.p, ct + lo * 16, m * 16, hipMemcpyHostToDevice));
+        if (per_block_keys) {
+            HIP_TRY(ctx, hipMemcpy(dkeys.p, keys + lo * 16, m * 16, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(dw.p, ks->w + lo * WORDS_ROWS, m * WORDS_ROWS, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(dkx.p, ks->kx + lo * cg.kxs, m * cg.kxs, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(dky.p, ks->ky + lo * cg.kys, m * cg.kys, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(dkz.p, ks->kz + lo * cg.kzs, m * cg.kzs, hipMemcpyHostToDevice));
+        }
+        const int rc = check_witness_impl(ctx, dpt.p, (per_block_keys || keys) ? dkeys.p : nullptr, per_block_keys, m, layout, dx.p, dy.p, dz.p,
+                                          ct ? dct.p : nullptr, &dks, reinterpret_cast<aesw_check_report *>(drep.p), nullptr,
+                                          /* skip the shared key slab */ !per_block_keys && lo != 0);
+        if (rc != AESW_OK) return rc;
+        aesw_check_report r;
+        HIP_TRY(ctx, hipMemcpy(&r, drep.p, sizeof r, hipMemcpyDeviceToHost));  // (synchronises with the null stream's launch)
+        report->blocks += r.blocks; report->keys += r.keys;
+        report->lookup_failures += r.lookup_failures; report->copy_failures += r.copy_failures;
+        report->gate_failures += r.gate_failures; report->input_failures += r.input_failures;
+        if (r.first != AESW_CHECK_NONE) {
+            // units of a stage count from its first block (the shared key slab is unit 0 of the batch as well)
+            const uint64_t unit = (r.first >> 20) + ((!per_block_keys && ((r.first >> 19) & 1)) ? 0 : lo);
+            const uint64_t f = unit << 20 | (r.first & 0xfffffu);
+            if (f < report->first) report->first = f;
+        }
+    }
     return AESW_OK;
 }
 

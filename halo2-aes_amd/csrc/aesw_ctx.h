@@ -14,7 +14,7 @@ struct aesw_ctx {
     uint8_t *d_tables = nullptr;  // 768 B
     uint8_t *d_fr_lut = nullptr;  // 256 x 32 B
     uint32_t *d_ftab[3] = {nullptr, nullptr, nullptr};  // flush descriptors per layout (aesw_layout.h "scheduled flush")
-    uint32_t *d_chktab[2] = {nullptr, nullptr};         // check tables of the DENSE / PACKED layout (aesw_check.h), built on first use
+    uint32_t *d_chktab[2] = {nullptr, nullptr};         // check tables of the DENSE / PACKED layout (aesw_check.h), uploaded by aesw_create
     // The scheduled key (FixedAes128Config::schedule_key, src/aes128.rs:143-152: `self.keys = Some(..)` replaces the key between
     // encrypt calls).  Round keys live in SLOTS of 256 B (176 used); every aesw_schedule_key_device takes the next slot of a small
     // ring and every scheduled-key launch bakes the pointer of the slot that is current when it is ENQUEUED, so a launch never sees

@@ -82,6 +82,7 @@ struct CheckParams {
     uint64_t *report;           // aesw_check_report as 7 x u64
     uint64_t n;
     uint32_t per_block_keys;
+    uint32_t skip_shared_key;   // one key slab for the batch: do not check it in this launch (a later chunk of a host-pointer call)
     uint32_t sx, sy, sz, kxs, kys, kzs, bi, img;  // strides, block image bytes, bytes of one wave's image region
 };
 hipError_t launch_check(const CheckParams &p, hipStream_t s);

@@ -1019,7 +1019,7 @@ __global__ void __launch_bounds__(256) check_kernel(const CheckParams a) {
     __syncthreads();
     const uint64_t nwaves = (uint64_t)gridDim.x * (blockDim.x / LANES), gwave = (uint64_t)blockIdx.x * (blockDim.x / LANES) + wave;
     CheckAcc acc;
-    if (gwave == 0 && lane == 0) { a.report[0] = a.n; a.report[1] = PBK ? a.n : 1; }
+    if (gwave == 0 && lane == 0) { a.report[0] = a.n; a.report[1] = PBK ? a.n : (a.skip_shared_key ? 0 : 1); }
     const uint32_t ct_off = tab[CHK_ROWS + 2 * (AES_ROWS - 16 + (lane & 15)) + 1] & 0xffffu;  // lanes 0..15: z of rows 1344 + lane
     const uint32_t w_off = tab[CHK_GATES + (lane & 15)] & 0xffffu;                              // lanes 0..15: words_column row `lane`
     if (!PBK) {  // one key slab for the whole batch: every wave keeps a copy; the first wave of the grid checks it
@@ -1027,7 +1027,7 @@ __global__ void __launch_bounds__(256) check_kernel(const CheckParams a) {
         sk.load(a, 0, lane);
         sk.store(kimg, lane);
         wave_lds_sync();
-        if (gwave == 0) check_key(img, a.table, t768, a.keys, 0, lane, LANES, acc);
+        if (gwave == 0 && !a.skip_shared_key) check_key(img, a.table, t768, a.keys, 0, lane, LANES, acc);
     }
     Staged<G::SX, 16> sx; Staged<G::SY, 16> sy; Staged<G::SZ, 16> sz;
     StagedKey<LAYOUT> skey;

@@ -406,6 +406,11 @@ int aesw_host_register(void *p, size_t bytes);
 int aesw_host_unregister(void *p);
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout,
                               uint8_t *w, uint8_t *kx, uint8_t *ky, uint8_t *kz, uint8_t *rk);
+/* host-pointer aesw_check_witness_device: every pointer is a host buffer, *report is written on the host when the call returns.
+ * The batch is uploaded and checked in stages of "chunk_blocks" blocks; units in report->first are batch-wide indices. */
+int aesw_check_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys, uint64_t n,
+                       int layout, const uint8_t *x, const uint8_t *y, const uint8_t *z, const uint8_t *ct,
+                       const aesw_key_slab *key_slab, aesw_check_report *report);
 /* host-pointer aesw_schedule_key_device: key is 16 host bytes, key_slab host buffers (optional) */
 int aesw_schedule_key(aesw_ctx *ctx, const uint8_t key[16], int layout, const aesw_key_slab *key_slab);
 int aesw_lookup_table(aesw_ctx *ctx, uint8_t *t0, uint8_t *t1, uint8_t *t2, uint8_t *t3);

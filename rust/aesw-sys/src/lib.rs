@@ -283,6 +283,20 @@ extern "C" {
         d_report: *mut aesw_check_report,
         stream: *mut c_void,
     ) -> c_int;
+    pub fn aesw_check_witness(
+        ctx: *mut aesw_ctx,
+        pt: *const u8,
+        keys: *const u8,
+        per_block_keys: c_int,
+        n: u64,
+        layout: c_int,
+        x: *const u8,
+        y: *const u8,
+        z: *const u8,
+        ct: *const u8,
+        key_slab: *const aesw_key_slab,
+        report: *mut aesw_check_report,
+    ) -> c_int;
     pub fn aesw_columns_alloc(
         ctx: *mut aesw_ctx,
         n: u64,

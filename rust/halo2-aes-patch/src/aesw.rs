@@ -138,6 +138,43 @@ impl AesWitness {
         Ok(w)
     }
 
+    /// `MockProver::assert_satisfied` for this witness without building the circuit (src/aes128.rs:409-418): every enabled
+    /// lookup, every `copy_advice()` pair, the round-constant gate and the plaintext / key literal rows, checked on the device
+    /// (`aesw_check_witness`: 2 ms per 2^20 blocks plus the upload).  `Ok(report)` with `report.satisfied()` for a valid witness.
+    pub fn verify(&self, plaintexts: &[[u8; 16]]) -> Result<sys::aesw_check_report, Error> {
+        if plaintexts.len() != self.n {
+            return Err(Error::Synthesis);
+        }
+        let mut ctx: *mut sys::aesw_ctx = std::ptr::null_mut();
+        check(unsafe { sys::aesw_create(&mut ctx, 0, S_BOX.as_ptr(), MUL_BY_2.as_ptr(), MUL_BY_3.as_ptr()) })?;
+        let slab = sys::aesw_key_slab {
+            w: self.key_words.as_ptr() as *mut u8,
+            kx: self.key_cols[0].as_ptr() as *mut u8,
+            ky: self.key_cols[1].as_ptr() as *mut u8,
+            kz: self.key_cols[2].as_ptr() as *mut u8,
+        };
+        let mut report = sys::aesw_check_report::default();
+        let rc = unsafe {
+            sys::aesw_check_witness(
+                ctx,
+                plaintexts.as_ptr() as *const u8,
+                self.key.as_ptr(),
+                0,
+                self.n as u64,
+                sys::AESW_LAYOUT_PACKED,
+                self.cols[0].as_ptr(),
+                self.cols[1].as_ptr(),
+                self.cols[2].as_ptr(),
+                std::ptr::null(),
+                &slab,
+                &mut report,
+            )
+        };
+        unsafe { sys::aesw_destroy(ctx) };
+        check(rc)?;
+        Ok(report)
+    }
+
     /// The byte the reference assigns to column `col` (0 = x, 1 = y, 2 = z) of the region at `at`; `None` for a
     /// cell the reference never assigns there.
     pub fn cell(&self, col: usize, at: At) -> Option<u8> {

@@ -352,7 +352,8 @@ def test_assemble_oneshot_geometry_equals_the_striding_kernel_and_synthesize(ctx
 
 def test_rescheduling_a_key_waits_for_launches_still_reading_the_old_one(pkg, oracle):
     """re-scheduling on stream A while stream B still reads the previous round keys was a write-after-read race.
-    The context now records an event behind every scheduled-key launch and aesw_schedule_key_device waits on it: a long
+    (Round 3 ordered the re-schedule behind ONE event, which lost all but the last reader stream; round 4 keeps the round keys in
+    a ring of slots with one event per reader stream -- tests/test_gpu_round4.py has the many-reader cases.)  One reader: a long
     launch with key A on one stream, key B scheduled on another stream right behind it, and the long launch's output is
     still key A's witness in every block; the next launch uses key B."""
     import torch

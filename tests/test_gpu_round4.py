@@ -726,3 +726,37 @@ def test_check_from_plain_c(pkg, tmp_path):
                     "-lamdhip64", "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe), "17"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok") and "first: block %d, lookup, row 40" % (((1 << 17) + 5) // 2) in out.stdout, out.stdout
+
+
+@pytest.mark.parametrize("pbk", [True, False])
+def test_host_pointer_checker_equals_the_device_one(pkg, oracle, pbk):
+    """aesw_check_witness (host buffers, staged upload) over several stages with a ragged last one reports what
+    aesw_check_witness_device reports for the same bytes: counts, and the first failure with batch-wide unit numbers; the shared
+    key slab is checked once, not once per stage."""
+    import torch
+    c = pkg.Context(0)
+    c.set_option("chunk_blocks", 1000)
+    rng = np.random.default_rng(90 + pbk)
+    n = 3 * 1000 + 77
+    pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    keys = rng.integers(0, 256, (n, 16) if pbk else 16, dtype=np.uint8)
+    w = oracle.encrypt_witness(pt, keys, layout=ol.PACKED)
+    k = oracle.key_schedule_witness(keys, layout=ol.PACKED)
+    cols, kcols = [w.x, w.y, w.z], [k.w, k.kx, k.ky, k.kz]
+    rep = c.check_witness_host(pt, keys, cols, kcols, ct=w.ct)
+    assert rep["satisfied"] and rep["blocks"] == n and rep["keys"] == (n if pbk else 1) and rep["first"] is None, rep
+    # failures in the third stage, in the last (ragged) stage and in a key slab
+    w.z[2500 * 608 + 9] ^= 1
+    w.x[(n - 1) * 1360 + 700] ^= 2
+    k.kx[(1200 * 400 if pbk else 0) + 44] ^= 4
+    if not pbk:
+        k.w[20] ^= 8   # the round-constant row of round 1: the gate
+    rep = c.check_witness_host(pt, keys, cols, kcols, ct=w.ct)
+    dev = c.check_witness(torch.from_numpy(pt).cuda(), torch.from_numpy(keys).cuda(),
+                          pkg.Witness(*[torch.from_numpy(a).cuda() for a in cols], None, None),
+                          pkg.KeyWitness(*[torch.from_numpy(a).cuda() for a in kcols], None), ct=torch.from_numpy(w.ct).cuda())
+    assert rep == dev and not rep["satisfied"], (rep, dev)
+    assert rep["first"][0] == (1200 if pbk else 0) and rep["first"][1], rep
+    if not pbk:
+        assert rep["gate_failures"] == 1
+    c.close()

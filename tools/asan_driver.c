@@ -280,6 +280,20 @@ int main(void) {
             if (aesw_check_witness_device(ctx, d_p, d_kk, 1, na, AESW_LAYOUT_VALUES, cc.x, cc.y, cc.z, NULL, &cc.key, d_rep, NULL) != AESW_ERR_INVALID_ARG) { fprintf(stderr, "check: VALUES layout accepted\n"); return 1; }
             HCHECK(hipFree(d_rep));
             CHECK(aesw_columns_free(ctx, &cc));
+            {   /* ... and the host-pointer form over three stages, the last one ragged: ref_* hold the witness of (hp, hk) */
+                uint8_t *hw = malloc(na * 96), *hkx = malloc(na * 400), *hky = malloc(na * 240), *hkz = malloc(na * 200);
+                aesw_key_slab hks2 = {hw, hkx, hky, hkz};
+                CHECK(aesw_encrypt_witness(ctx, hp, hk, 1, na, AESW_LAYOUT_PACKED, ref_x, ref_y, ref_z, NULL, &hks2));
+                CHECK(aesw_set_option(ctx, "chunk_blocks", 30000));
+                CHECK(aesw_check_witness(ctx, hp, hk, 1, na, AESW_LAYOUT_PACKED, ref_x, ref_y, ref_z, NULL, &hks2, &rep));
+                if (rep.blocks != na || rep.keys != na || rep.first != AESW_CHECK_NONE) { fprintf(stderr, "host check: not satisfied\n"); return 1; }
+                ref_y[(na - 1) * 1056 + 3] ^= 1;
+                CHECK(aesw_check_witness(ctx, hp, hk, 1, na, AESW_LAYOUT_PACKED, ref_x, ref_y, ref_z, NULL, &hks2, &rep));
+                if (rep.first == AESW_CHECK_NONE || AESW_CHECK_UNIT(rep.first) != na - 1) { fprintf(stderr, "host check: the last block's change went unnoticed\n"); return 1; }
+                ref_y[(na - 1) * 1056 + 3] ^= 1;
+                CHECK(aesw_set_option(ctx, "chunk_blocks", 1 << 15));
+                free(hw); free(hkx); free(hky); free(hkz);
+            }
         }
         {   /* round 4: the scheduled key's slot ring.  Twenty reader streams (more than a slot tracks: folding), re-schedules
              * on rings of 1, 2 and 4 slots, a lone launch dealt out by "split_small"; the last key's output is checked */
