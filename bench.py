@@ -1068,7 +1068,11 @@ def main():
             dist.destroy_process_group()
         except Exception:
             any_failed = True
-        dog.disarm()
+        dog.disarm()  # cancels the last timer thread
+        try:
+            ctx.close()
+        except Exception:
+            pass
         if rank == 0:
             if any_failed:
                 line["error"] = "N>1 tail failed: %s" % (", ".join(failed) or "on another rank")
@@ -1078,6 +1082,12 @@ def main():
         return
     if rank == 0:
         print(json.dumps(line), flush=True)
+    # leave nothing behind: the context's streams, events, cached arenas and page-locked buffers go with it; the library's
+    # copy threads are joined inside every call; no watchdog timer exists at N = 1
+    try:
+        ctx.close()
+    except Exception:
+        pass
     if line.get("error"):
         sys.exit(5)
 

@@ -374,6 +374,9 @@ class Context:
     # -- lifetime
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
+            for _group, comm in list(getattr(self, "_sharding_comms", {}).values()):  # communicators sharding.gather_columns made for this context
+                comm.close()
+            self.__dict__.pop("_sharding_comms", None)
             for cols in list(getattr(self, "_arenas", {}).values()):
                 self._lib.aesw_columns_free(self._h, C.byref(cols))
             self._arenas = {}
