@@ -470,11 +470,14 @@ class Watchdog:
     rank 0 prints the line with the phase that stalled and EVERY rank exits non-zero."""
 
     def __init__(self, rank, line):
-        self.rank, self.line, self.timer, self.phase = rank, line, None, None
+        self.rank, self.line, self.timer, self.phase, self.optional_key = rank, line, None, None, None
 
-    def arm(self, phase, seconds):
+    def arm(self, phase, seconds, optional_key=None):
+        """optional_key: the phase is an optional extra measured after everything else (the C ABI's own RCCL gather, never run
+        with real ranks before): a stall is recorded under line[optional_key] as a non-fatal error and the job still ends with
+        status 0 -- the scaling measurement it rides on is already in the line and must not be voided by it."""
         self.disarm()
-        self.phase = phase
+        self.phase, self.optional_key = phase, optional_key
         self.timer = threading.Timer(seconds, self._fire)
         self.timer.daemon = True
         self.timer.start()
@@ -485,6 +488,11 @@ class Watchdog:
             self.timer = None
 
     def _fire(self):
+        if self.optional_key is not None:
+            if self.rank == 0:
+                self.line[self.optional_key] = {"error": "phase '%s' timed out" % self.phase, "fatal": False}
+                print(json.dumps(self.line), flush=True)
+            os._exit(0)
         if self.rank == 0:
             self.line["error"] = "phase '%s' timed out" % self.phase
             print(json.dumps(self.line), flush=True)
@@ -1040,13 +1048,14 @@ def main():
         if not a.no_extras and a.backend == "nccl" and a.gather_path != "cabi":
             # LAST, because it is the one step that has never run with real ranks: the C ABI's own RCCL gather (what a host without
             # torch calls) over 2^20-block columns.  Everything measured so far is already in the line: a stall
-            # here ends the job through the watchdog (status 3) with that line printed; an exception is recorded and is not fatal.
+            # here ends the job through the watchdog with that line printed and gather_cabi = {error, fatal: false} (status 0: an
+            # optional extra must not void the scaling measurement it rides on); an exception is recorded the same way.
             try:
-                dog.arm("gather_cabi warm-up (second RCCL communicator beside torch's: ncclCommInitRank + peer channels)", 120.0)
+                dog.arm("gather_cabi warm-up (second RCCL communicator beside torch's: ncclCommInitRank + peer channels)", 120.0, optional_key="gather_cabi")
                 ng = 1 << 20
                 wg = ctx.alloc_witness(ng, layout)
                 timed_gather(wg, ng, cabi=True)
-                dog.arm("gather_cabi", 60.0)
+                dog.arm("gather_cabi", 60.0, optional_key="gather_cabi")
                 dtg = timed_gather(wg, ng, cabi=True)
                 dog.disarm()
                 if rank == 0:
