@@ -181,7 +181,7 @@ int aesw_key_copy_graph(aesw_copy_edge edges[AESW_KEY_COPIES]);
  *    aesw_encrypt_witness_batches_device: one event per distinct reader stream since the slot was written, all of them waited on
  *    (on the scheduling stream, no host wait) by the schedule that takes the slot again.  More than 16 distinct reader streams
  *    per slot are folded (the 17th stream waits for the first one's launches AFTER its own launch).  Streams that carried
- *    scheduled-key launches may be destroyed at any time (hipStreamDestroy drains them).
+ *    scheduled-key launches may be destroyed at any time (hipStreamDestroy drains a stream in the ROCm runtime).
  *  - Under hipGraph capture nothing can be tracked per replay, so slots are frozen instead: a schedule captured into a graph
  *    writes a slot of its own, and a slot read by a captured launch is pinned -- in both cases the ring never hands that slot
  *    out again (256 B each, until aesw_destroy).  A captured launch therefore reads, on every replay, the key that was current

@@ -759,4 +759,11 @@ def test_host_pointer_checker_equals_the_device_one(pkg, oracle, pbk):
     assert rep["first"][0] == (1200 if pbk else 0) and rep["first"][1], rep
     if not pbk:
         assert rep["gate_failures"] == 1
+    # an empty batch is satisfied (nothing to check), on both forms
+    empty = c.check_witness_host(pt[:0], keys[:0] if pbk else keys, [a[:0] for a in cols], kcols if not pbk else [a[:0] for a in kcols])
+    assert empty["satisfied"] and empty["blocks"] == 0 and empty["first"] is None
+    e_dev = c.check_witness(torch.from_numpy(pt[:0].copy()).cuda(), torch.from_numpy(keys).cuda()[:0] if pbk else torch.from_numpy(keys).cuda(),
+                            pkg.Witness(*[torch.empty(0, dtype=torch.uint8, device="cuda")] * 3, None, None),
+                            pkg.KeyWitness(*[torch.from_numpy(a).cuda() for a in kcols], None))
+    assert e_dev["satisfied"] and e_dev["blocks"] == 0
     c.close()
