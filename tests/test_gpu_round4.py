@@ -767,3 +767,50 @@ def test_host_pointer_checker_equals_the_device_one(pkg, oracle, pbk):
                             pkg.KeyWitness(*[torch.from_numpy(a).cuda() for a in kcols], None))
     assert e_dev["satisfied"] and e_dev["blocks"] == 0
     c.close()
+
+
+def test_gather_moves_the_right_bytes_between_six_processes(pkg, tmp_path):
+    """aesw_gather_columns_device run FOR REAL by six processes sharing the one GPU, against a functional stand-in for librccl
+    (tests/mock_rccl/shm_rccl.c: a message is a file in a tmpfs directory; NCCL's pairing rule -- k-th send to a peer with the k-th
+    receive from it, equal sizes -- is enforced).  Ragged counts, one empty rank, a max_message that cuts every range into pieces,
+    root 0 and root 3: every byte of the gathered columns on the root is the byte its owner put there.  What this cannot show is
+    xGMI itself; what it does show is that the C ABI's exchange is correct as a distributed program, not only as a call log."""
+    import os
+    import shutil
+    import subprocess
+    from pathlib import Path
+    ROOT = Path(__file__).resolve().parent.parent
+    mock_dir, lib_dir = ROOT / "tests" / "mock_rccl", ROOT / "halo2-aes_amd"
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-o", str(tmp_path / "librccl.so"),
+                    str(mock_dir / "shm_rccl.c"), "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    exe = tmp_path / "gather_driver"
+    subprocess.run(["gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I", str(ROOT / "include"), "-I", "/opt/rocm/include",
+                    str(mock_dir / "gather_driver.c"), "-o", str(exe), "-L", str(lib_dir), "-laesw", "-L", "/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    world, counts, maxmsg = 6, [700, 301, 0, 1234, 48, 917], 100000
+    for root in (0, 3):
+        box = Path("/dev/shm") / ("aesw_gather_%d_%d" % (os.getpid(), root))
+        box.mkdir()
+        try:
+            env = dict(os.environ, SHM_RCCL_DIR=str(box), GATHER_ROOT=str(root), GATHER_DATA="1",
+                       LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+            procs = [subprocess.Popen([str(exe), str(world), str(r), str(maxmsg)] + [str(c) for c in counts], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True) for r in range(world)]
+            outs = [p.communicate(timeout=180)[0] for p in procs]
+            for r, (p, o) in enumerate(zip(procs, outs)):
+                assert p.returncode == 0 and "ok" in o, (root, r, o)
+            assert "data ok" in outs[root], outs[root]
+            assert not list(box.iterdir()), "messages nobody received: %r" % [f.name for f in box.iterdir()]
+        finally:
+            shutil.rmtree(box, ignore_errors=True)
+    # the stand-in is not lenient: a peer that cuts its range differently from the root (DESIGN 7: max_message must agree) fails the exchange
+    box = Path("/dev/shm") / ("aesw_gather_%d_bad" % os.getpid())
+    box.mkdir()
+    try:
+        env = dict(os.environ, SHM_RCCL_DIR=str(box), GATHER_DATA="1", LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        procs = [subprocess.Popen([str(exe), "2", str(r), str(mm), "100", "100"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for r, mm in ((0, 9000), (1, 7000))]
+        outs = [p.communicate(timeout=180)[0] for p in procs]
+        assert procs[0].returncode != 0 and "cut the range differently" in outs[0], outs
+    finally:
+        shutil.rmtree(box, ignore_errors=True)
