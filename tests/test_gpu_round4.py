@@ -769,8 +769,9 @@ def test_host_pointer_checker_equals_the_device_one(pkg, oracle, pbk):
     c.close()
 
 
-def test_gather_moves_the_right_bytes_between_six_processes(pkg, tmp_path):
-    """aesw_gather_columns_device run FOR REAL by six processes sharing the one GPU, against a functional stand-in for librccl
+def test_gather_moves_the_right_bytes_between_five_processes(pkg, tmp_path):
+    """aesw_gather_columns_device run FOR REAL by five processes sharing the one GPU (with the test runner that makes six GPU users,
+    the box's limit), against a functional stand-in for librccl
     (tests/mock_rccl/shm_rccl.c: a message is a file in a tmpfs directory; NCCL's pairing rule -- k-th send to a peer with the k-th
     receive from it, equal sizes -- is enforced).  Ragged counts, one empty rank, a max_message that cuts every range into pieces,
     root 0 and root 3: every byte of the gathered columns on the root is the byte its owner put there.  What this cannot show is
@@ -787,7 +788,7 @@ def test_gather_moves_the_right_bytes_between_six_processes(pkg, tmp_path):
     subprocess.run(["gcc", "-O1", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I", str(ROOT / "include"), "-I", "/opt/rocm/include",
                     str(mock_dir / "gather_driver.c"), "-o", str(exe), "-L", str(lib_dir), "-laesw", "-L", "/opt/rocm/lib", "-lamdhip64",
                     "-Wl,-rpath," + str(lib_dir), "-Wl,-rpath,/opt/rocm/lib"], check=True)
-    world, counts, maxmsg = 6, [700, 301, 0, 1234, 48, 917], 100000
+    world, counts, maxmsg = 5, [700, 301, 0, 1234, 917], 100000
     for root in (0, 3):
         box = Path("/dev/shm") / ("aesw_gather_%d_%d" % (os.getpid(), root))
         box.mkdir()
