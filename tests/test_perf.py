@@ -20,17 +20,21 @@ def gpu():
     return torch
 
 
-def _launch_us(torch, c, pkg, dpt, dkeys, w, reps=5):
-    c.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, key_slab=True)
+def _launch_us(torch, c, pkg, dpt, dkeys, w, reps=7, per=10):
+    """Microseconds per launch: `per` launches between two events, median of `reps` such measurements (a single launch's event
+    time wanders by 3 % on one and the same memory)."""
+    for _ in range(3):
+        c.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, key_slab=True)
     torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        c.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, key_slab=True)
+        for _ in range(per):
+            c.encrypt_witness(dpt, dkeys, layout=pkg.LAYOUT_PACKED, out=w, key_slab=True)
         e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.append(e0.elapsed_time(e1) * 1e3 / per)
     return sorted(ts)[len(ts) // 2]
 
 
