@@ -164,3 +164,30 @@ def test_first_failure_is_the_smallest_unit(model, oracle):
     w.y[12 * sy + 5] ^= 1
     r = _check(model, tab, ol.PACKED, pt, keys, True, w, k)
     assert r["first"][0] == 15 and r["first"][1]
+
+
+def test_the_tables_are_inputs_of_the_check_too(model):
+    """src/table.rs builds the lookup table from whatever src/constant.rs holds; so does the checker.  A witness made with a random
+    S-box and random (non-xtime) mul tables satisfies the check under THOSE tables -- including the oracle's own MockProver on a
+    real circuit -- and fails it under the reference's; FIPS tables (S_BOX[255] = 22) differ from the reference's in exactly the
+    rows whose S-box input is 0xff."""
+    rng = np.random.default_rng(6)
+    tables = (rng.permutation(256).astype(np.uint8), rng.integers(0, 256, 256, dtype=np.uint8), rng.integers(0, 256, 256, dtype=np.uint8))
+    o2 = ol.Oracle(tables=tables)
+    pt, keys = rng.integers(0, 256, (30, 16), dtype=np.uint8), rng.integers(0, 256, (30, 16), dtype=np.uint8)
+    for layout in (ol.DENSE, ol.PACKED):
+        w, k = o2.encrypt_witness(pt, keys, layout=layout), o2.key_schedule_witness(keys, layout=layout)
+        assert _check(model, np.concatenate(tables), layout, pt, keys, True, w, k, ct=w.ct)["first"] is None
+        ref = _check(model, _tab(ol.Oracle()), layout, pt, keys, True, w, k, ct=w.ct)
+        assert ref["lookup"] > 1000 and ref["copy"] == 0 and ref["gate"] == 0 and ref["input"] == 0  # the copies and literals do not depend on the tables
+    with o2.circuit(11, 2, keys[0], pt[:1]) as circ:
+        assert circ.verify()[0] == 0
+    # the reference's table against FIPS-197's: one entry apart
+    o = ol.Oracle()
+    pt[3], keys[3] = 0xFF, 0  # pt ^ key = 0xff in every byte: round 1's S-box rows read entry 255
+    w, k = o.encrypt_witness(pt, keys, layout=ol.PACKED), o.key_schedule_witness(keys, layout=ol.PACKED)
+    fips = _tab(o)
+    assert fips[255] == 23
+    fips[255] = 22
+    r = _check(model, fips, ol.PACKED, pt, keys, True, w, k)
+    assert r["lookup"] >= 16 and r["first"][0] <= 3 and r["copy"] == 0
