@@ -257,6 +257,23 @@ __device__ __forceinline__ void flush_contig(const uint8_t *lds, uint32_t stage,
     }
 }
 
+// A whole contiguous range of BYTES bytes (a full wave's sixteen units of one column) as PIECE-byte pieces: exactly
+// ceil(BYTES / PIECE / 64) store instructions.
+template <int PIECE, int BYTES, int NT>
+__device__ __forceinline__ void flush_range(const uint8_t *lds, uint32_t stage, uint8_t *g, int lane) {
+    using V = typename PieceT<PIECE>::type;
+    static_assert(BYTES % PIECE == 0, "whole pieces");
+    constexpr int TOTAL = BYTES / PIECE;
+#pragma unroll
+    for (int p0 = 0; p0 < TOTAL; p0 += LANES) {
+        const int p = p0 + lane;
+        if (p0 + LANES <= TOTAL || p < TOTAL) {
+            const V v = *reinterpret_cast<const V *>(lds + stage + p * PIECE);
+            gstore<NT>(reinterpret_cast<V *>(g + (size_t)p * PIECE), v);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // per-wave LDS footprints
 // ---------------------------------------------------------------------------
@@ -350,7 +367,7 @@ __device__ __forceinline__ void key_phase(uint8_t *lds, uint32_t stage, uint32_t
     }
 }
 
-template <int L, int NT>
+template <int L, int NT, bool WHOLE_KZ = false>
 __device__ __forceinline__ void key_flush(const uint8_t *lds, uint32_t stage, const KeyOut &o, uint64_t blk0,
                                           int nvalid, int lane) {
     using G = Geo<L>;
@@ -358,8 +375,21 @@ __device__ __forceinline__ void key_flush(const uint8_t *lds, uint32_t stage, co
     if (o.w) flush_contig<16, WORDS_ROWS, NT>(lds, stage + St::KW, o.w + blk0 * WORDS_ROWS, nvalid, lane);
     if (o.kx) flush_contig<16, G::KXS, NT>(lds, stage + St::KX, o.kx + blk0 * G::KXS, nvalid, lane);
     if (o.ky) flush_contig<16, G::KYS, NT>(lds, stage + St::KY, o.ky + blk0 * G::KYS, nvalid, lane);
-    if (o.kz) flush_contig<(G::KZS % 16 == 0 ? 16 : 8), G::KZS, NT>(lds, stage + St::KZ, o.kz + blk0 * G::KZS, nvalid, lane);
+    if (o.kz) {
+        // packed kz is 200 B per key -- not a multiple of 16 -- but a FULL wave's sixteen keys are one contiguous, 128-byte aligned
+        // range of 3 200 B on both sides (blk0 is a multiple of 16; St::KZ and the stage base are multiples of 16): whole-range
+        // 16-byte pieces halve the store instructions of this column (round 4: key_kernel +5 ... 7 % in one-process A/Bs on three
+        // leases, tools/key_ab.py).  A ragged last wave keeps per-key 8-byte pieces, and so does the key phase fused into
+        // encrypt_kernel (WHOLE_KZ false), where the same change measured -0.5 % +- 0.6: left as it was.
+#ifdef AESW_KZ_PER_KEY  /* private A/B build (tools/key_ab.py): round 3's per-key 8-byte pieces */
+        if (false) {}
+#else
+        if (WHOLE_KZ && G::KZS % 16 != 0 && nvalid == BPW) flush_range<16, BPW * G::KZS, NT>(lds, stage + St::KZ, o.kz + blk0 * G::KZS, lane);
+#endif
+        else flush_contig<(G::KZS % 16 == 0 ? 16 : 8), G::KZS, NT>(lds, stage + St::KZ, o.kz + blk0 * G::KZS, nvalid, lane);
+    }
 }
+static_assert((BPW * Geo<PACKED>::KZS) % 16 == 0 && Stage<PACKED>::KZ % 16 == 0 && Stage<PACKED>::KEY_BYTES % 16 == 0, "whole-range kz pieces");
 
 // ---------------------------------------------------------------------------
 // encrypt witness kernel
@@ -578,7 +608,7 @@ __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     uint32_t rk_unused[11];
     key_phase<L, true, true>(lds, stage, rk_w, kw, blk, w, tab, rk_unused);
     wave_lds_fence();
-    key_flush<L, NT>(lds, stage, a.key, blk0, nvalid, lane);
+    key_flush<L, NT, true>(lds, stage, a.key, blk0, nvalid, lane);
     if (a.rk) flush_contig<16, RK_BYTES, NT>(lds, rk_w, a.rk + blk0 * RK_BYTES, nvalid, lane);
 }
 
