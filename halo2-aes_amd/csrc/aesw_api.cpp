@@ -532,7 +532,7 @@ static void parallel_copy(const std::vector<CopyJob> &jobs, int threads) noexcep
     for (std::thread &t : pool) t.join();
 }
 
-static int auto_waves_key(const aesw_ctx *ctx, int layout);
+static int auto_waves_key(const aesw_ctx *ctx, int layout, bool want_rk);
 
 int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!ctx || !name || !value) return AESW_ERR_INVALID_ARG;
@@ -541,7 +541,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     // what a launch really uses (0 = auto resolved, values above the layout's maximum clamped): packed layout
     if (!std::strcmp(name, "effective_waves_shared")) { *value = auto_waves(ctx, AESW_LAYOUT_PACKED, false); return AESW_OK; }
     if (!std::strcmp(name, "effective_waves_pbk")) { *value = auto_waves(ctx, AESW_LAYOUT_PACKED, true); return AESW_OK; }
-    if (!std::strcmp(name, "effective_waves_key")) { *value = auto_waves_key(ctx, AESW_LAYOUT_PACKED); return AESW_OK; }
+    if (!std::strcmp(name, "effective_waves_key")) { *value = auto_waves_key(ctx, AESW_LAYOUT_PACKED, false); return AESW_OK; }
     if (!std::strcmp(name, "nt_stores")) { *value = ctx->nt == 1; return AESW_OK; }
     if (!std::strcmp(name, "store_mode")) { *value = ctx->nt; return AESW_OK; }
     if (!std::strcmp(name, "key_store_mode")) { *value = ctx->key_nt; return AESW_OK; }
@@ -598,8 +598,13 @@ static int auto_waves(const aesw_ctx *ctx, int layout, bool pbk) {
 }
 
 // key_kernel alone (tools/keysweep.py, 2^20 keys): packed 4-wave groups, dense 2-wave groups
-static int auto_waves_key(const aesw_ctx *ctx, int layout) {
-    return ctx->waves_pbk ? ctx->waves_pbk : (layout == AESW_LAYOUT_DENSE ? 2 : 4);
+static int auto_waves_key(const aesw_ctx *ctx, int layout, bool want_rk) {
+    // packed, witness only (no round-key output: no 2.8 KB round-key staging per wave since round 4): three 3-wave groups fit a CU
+    // (45.7 KB each) and run 143.7 us against 146.3 for 4-wave groups and 148.0 / 154.9 for 2 / 1 (tools/keyarena.py,
+    // profiles/r04_study/key_kernel_kz.md); with round keys a 3-wave group is 54 KB (two per CU): 4-wave groups as before
+    if (ctx->waves_pbk) return ctx->waves_pbk;
+    if (layout == AESW_LAYOUT_DENSE) return 2;
+    return want_rk ? 4 : 3;
 }
 
 int aesw_schedule_key_device(aesw_ctx *ctx, const uint8_t *d_key, int layout, const aesw_key_slab *ks, void *stream) {
@@ -799,7 +804,7 @@ int aesw_key_schedule_witness_device(aesw_ctx *ctx, const uint8_t *d_keys, uint6
     DeviceGuard g(ctx->device);
     if (!g.ok) return AESW_ERR_NO_DEVICE;
     KeyParams kp{d_keys, ctx->d_tables, KeyOut{d_w, d_kx, d_ky, d_kz}, d_rk, n, 0, 0};
-    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves_key(ctx, layout), ctx->key_nt, ctx->xcd_remap, reinterpret_cast<hipStream_t>(stream)));
+    HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, auto_waves_key(ctx, layout, d_rk != nullptr), ctx->key_nt, ctx->xcd_remap, reinterpret_cast<hipStream_t>(stream)));
     return AESW_OK;
 }
 

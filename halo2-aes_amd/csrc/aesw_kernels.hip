@@ -589,7 +589,9 @@ template <int L, bool XT, int NT>
 __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     using St = Stage<L>;
-    constexpr int WAVE_LDS = St::KEY_BYTES + St::RK_BYTES_W;
+    // the round-key staging (176 B per key) exists only when the caller asked for round keys (round 4: the witness-only form -- what
+    // bench.py and aesw_columns_alloc's key-only arenas run -- neither reserves nor writes it)
+    const int WAVE_LDS = St::KEY_BYTES + (a.rk ? St::RK_BYTES_W : 0);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6;
     const int blk = lane >> 2, w = lane & 3;
@@ -606,7 +608,8 @@ __global__ void __launch_bounds__(256) key_kernel(const KeyParams a) {
     if (nvalid == 0) return;
     const uint32_t kw = blk < nvalid ? reinterpret_cast<const uint32_t *>(a.keys)[(blk0 + blk) * 4 + w] : 0u;
     uint32_t rk_unused[11];
-    key_phase<L, true, true>(lds, stage, rk_w, kw, blk, w, tab, rk_unused);
+    if (a.rk) key_phase<L, true, true>(lds, stage, rk_w, kw, blk, w, tab, rk_unused);
+    else key_phase<L, true, false>(lds, stage, rk_w, kw, blk, w, tab, rk_unused);
     wave_lds_fence();
     key_flush<L, NT, true>(lds, stage, a.key, blk0, nvalid, lane);
     if (a.rk) flush_contig<16, RK_BYTES, NT>(lds, rk_w, a.rk + blk0 * RK_BYTES, nvalid, lane);
@@ -1211,7 +1214,7 @@ static hipError_t launch_key_t(const KeyParams &p0, int waves, uint32_t xr, hipS
     KeyParams p = p0;
     p.ngroups = (uint32_t)groups;
     p.xcd_remap = xr;
-    const size_t lds = TAB_BYTES + (size_t)waves * (Stage<L>::KEY_BYTES + Stage<L>::RK_BYTES_W);
+    const size_t lds = TAB_BYTES + (size_t)waves * (Stage<L>::KEY_BYTES + (p.rk ? Stage<L>::RK_BYTES_W : 0));
     {
         hipError_t e = allow_large_lds(reinterpret_cast<const void *>(&key_kernel<L, XT, NT>), lds);
         if (e != hipSuccess) return e;

@@ -470,7 +470,7 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * backing for the next aesw_columns_alloc of the same shape: the default; 0 = off, and releases what is cached), "arena_cache_max_mb"
  * (bytes the cache may hold, default 65536), "arena_probe_budget_ms" (wall-time bound of one placement search, default 3000, 0 = none).
  * aesw_get_option reads back every option aesw_set_option accepts, plus "effective_waves_shared" / "effective_waves_pbk" /
- * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied), and "effective_copy_threads", and the
+ * "effective_waves_key": the group size a packed-layout launch really uses (auto resolved, limits applied; for the key kernel: its witness-only form, without round-key output), and "effective_copy_threads", and the
  * read-only statistics "key_reader_waits" (reader events schedules have waited on), "key_slots_allocated", "key_slots_pinned",
  * "arena_cache_hits", "arena_cached_bytes".
  * Unknown -> INVALID_ARG */

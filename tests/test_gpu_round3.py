@@ -110,7 +110,7 @@ def test_every_settable_option_reads_back(pkg):
     c.set_option("waves_shared", 4)
     c.set_option("waves_pbk", 0)
     assert c.get_option("waves_shared") == 4 and c.get_option("effective_waves_shared") == 3
-    assert c.get_option("effective_waves_pbk") == 1 and c.get_option("effective_waves_key") == 4
+    assert c.get_option("effective_waves_pbk") == 1 and c.get_option("effective_waves_key") == 3
     with pytest.raises(pkg.AeswError):
         c.get_option("no_such_option")
     c.close()
