@@ -421,7 +421,7 @@ def cpu_baseline(per_block_keys, n_target_seconds=12.0):
     }
 
 
-def c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=True, samples=6):
+def c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=True, samples=6, check_stream=True):
     """BASELINE configs[4] on this rank's GPU: aesw_encrypt_witness_stream over pt4 with a CHEAP consumer -- the
     pt ^ rk0 check on every chunk (what a host's assign loop would at least have to touch) plus a copy of the first
     256 blocks of `samples` chunks.  The oracle comparison of those copies happens AFTER the stream has ended and
@@ -449,6 +449,20 @@ def c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=True, samples=6):
     ctx.encrypt_witness_stream(pt4, None, consume, layout=lay)
     dt = time.perf_counter() - t0
     st = ctx.last_stream_stats()
+    chk = {"blocks": 0, "satisfied": True}
+    if check_stream and lay != pkg.LAYOUT_VALUES:
+        # the same stream once more with option "stream_check": every chunk checked on the device behind its kernel
+        # (aesw_check_witness_device) on its way to the host -- all n4 blocks certified; timed by itself so that the figure above
+        # stays comparable with earlier rounds
+        ctx.set_option("stream_check", 1)
+        try:
+            t1 = time.perf_counter()
+            ctx.encrypt_witness_stream(pt4, None, lambda *args: 0, layout=lay)
+            chk = dict(ctx.last_stream_check(), seconds=time.perf_counter() - t1)
+        finally:
+            ctx.set_option("stream_check", 0)
+        if not chk["satisfied"] or chk["blocks"] != n4:
+            bad[0] += 1
     per = sum(strides)
     if verify:
         import oracle_lib
@@ -462,7 +476,8 @@ def c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=True, samples=6):
             "kernel_s": st["kernel_ns"] * 1e-9, "kernel_blocks_per_s": n4 / (st["kernel_ns"] * 1e-9),
             "d2h_s": st["d2h_ns"] * 1e-9, "d2h_GBps": st["bytes_to_host"] / (st["d2h_ns"] * 1e-9) / 1e9,
             "consumer_s": st["consumer_ns"] * 1e-9, "wait_s": st["wait_ns"] * 1e-9, "chunks": st["chunks"],
-            "sampled_chunks_verified_after_the_stream": len(kept) if verify else 0, "mismatches": bad[0]}
+            "sampled_chunks_verified_after_the_stream": len(kept) if verify else 0, "mismatches": bad[0],
+            "stream_check": {k_: v_ for k_, v_ in chk.items() if k_ != "first"}}
 
 
 class Watchdog:
@@ -970,7 +985,7 @@ def main():
                     torch.cuda.synchronize()
                     dist.barrier()
                     t0 = time.perf_counter()
-                    r4 = c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=False)
+                    r4 = c4_stream(pkg, ctx, pt4, key4, lay, olay, verify=False, check_stream=False)
                     torch.cuda.synchronize()
                     t_rank = time.perf_counter() - t0
                     dist.barrier()

@@ -103,6 +103,7 @@ SYMBOLS = {
     "aesw_expand_fr_device": (_I, [_P, _P, _U64, _P, _P]),
     "aesw_check_witness_device": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), _P, _P]),
     "aesw_check_witness": (_I, [_P, _P, _P, _I, _U64, _I, _P, _P, _P, _P, C.POINTER(KeySlab), C.POINTER(CheckReport)]),
+    "aesw_last_stream_check": (_I, [_P, C.POINTER(CheckReport)]),
     "aesw_assemble_advice_device": (_I, [_P, _U32, _U32, _U64, _I, _P, _P, _P, C.POINTER(KeySlab), _I, _P, _P]),
     "aesw_columns_alloc": (_I, [_P, _U64, _I, _I, _I, C.POINTER(Columns)]),
     "aesw_columns_free": (_I, [_P, C.POINTER(Columns)]),
@@ -653,6 +654,16 @@ class Context:
         first = None if v[6] == 0xFFFFFFFFFFFFFFFF else (v[6] >> 20, bool((v[6] >> 19) & 1), (v[6] >> 16) & 7, v[6] & 0xFFFF)
         return {"blocks": v[0], "keys": v[1], "lookup_failures": v[2], "copy_failures": v[3], "gate_failures": v[4], "input_failures": v[5],
                 "first": first, "satisfied": not any(v[2:6])}
+
+    def last_stream_check(self):
+        """aesw_last_stream_check: what option "stream_check" found over the chunks of the last encrypt_witness_stream call."""
+        rep = CheckReport()
+        self._check(self._lib.aesw_last_stream_check(self._h, C.byref(rep)), "aesw_last_stream_check")
+        f = int(rep.first)
+        out = {k_: int(getattr(rep, k_)) for k_ in ("blocks", "keys", "lookup_failures", "copy_failures", "gate_failures", "input_failures")}
+        out.update(first=None if f == 0xFFFFFFFFFFFFFFFF else (f >> 20, bool((f >> 19) & 1), (f >> 16) & 7, f & 0xFFFF),
+                   satisfied=not any(out[k_] for k_ in ("lookup_failures", "copy_failures", "gate_failures", "input_failures")))
+        return out
 
     def check_witness_host(self, pt, keys, cols, key_cols, layout: int = K.LAYOUT_PACKED, ct=None):
         """aesw_check_witness: the same check for a witness in HOST memory (numpy uint8 arrays: cols = (x, y, z), key_cols =

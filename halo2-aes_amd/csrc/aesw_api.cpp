@@ -479,6 +479,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "copy_threads")) { if (value < -1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->copy_threads = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "key_slots")) { if (value < 1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->key_ring = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "split_small")) { if (value < 0 || value > 8) return AESW_ERR_INVALID_ARG; ctx->split_small = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "stream_check")) { if (value != 0 && value != 1) return AESW_ERR_INVALID_ARG; ctx->stream_check = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache")) {  // 0 also releases what is cached now
         if (value != 0 && value != 1) return AESW_ERR_INVALID_ARG;
         ctx->arena_cache_on = (int)value;
@@ -561,6 +562,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "effective_copy_threads")) { *value = auto_copy_threads(ctx); return AESW_OK; }
     if (!std::strcmp(name, "key_slots")) { *value = ctx->key_ring; return AESW_OK; }
     if (!std::strcmp(name, "split_small")) { *value = ctx->split_small; return AESW_OK; }
+    if (!std::strcmp(name, "stream_check")) { *value = ctx->stream_check; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache")) { *value = ctx->arena_cache_on; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache_max_mb")) { *value = (int64_t)(ctx->arena_cache_max_bytes >> 20); return AESW_OK; }
     if (!std::strcmp(name, "arena_probe_budget_ms")) { *value = ctx->arena_probe_budget_ms; return AESW_OK; }
@@ -1132,6 +1134,23 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
     for (int s = 0; s < 2; ++s)
         for (int c = 0; c < 3; ++c) col_off[s][c] = take(chunk * strides[c]);
     for (int c = 0; c < 3; ++c) { boff[c] = bneed; bneed += (chunk * strides[c] + 255) / 256 * 256; }
+    // "stream_check": every chunk is checked on the device behind its kernel (aesw_check.h).  Needs the key slab(s) the blocks' AddRoundKey
+    // rows copy from -- one for a shared / scheduled key (made once, below), one per block with per-block keys (emitted by the chunk's
+    // own launch into two more scratch sets) -- and one report per chunk, summed after the last one.
+    const bool checking = ctx->stream_check && layout != AESW_LAYOUT_VALUES;
+    const uint64_t n_chunks = (n + chunk - 1) / chunk;
+    const size_t kstr[3] = {aesw_key_column_stride(layout, 0), aesw_key_column_stride(layout, 1), aesw_key_column_stride(layout, 2)};
+    size_t ks_off[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, o_rep = 0;
+    if (checking) {
+        const uint64_t nk = pbk ? chunk : 1;
+        for (int s = 0; s < (pbk ? 2 : 1); ++s) {
+            ks_off[s][0] = take(nk * WORDS_ROWS);
+            for (int c = 0; c < 3; ++c) ks_off[s][1 + c] = take(nk * kstr[c]);
+        }
+        if (!pbk) for (int c = 0; c < 4; ++c) ks_off[1][c] = ks_off[0][c];
+        o_rep = take(n_chunks * sizeof(aesw_check_report));
+    }
+    ctx->stream_report = aesw_check_report{0, 0, 0, 0, 0, 0, AESW_CHECK_NONE};
     rc = ensure_scratch(ctx, off);
     if (rc != AESW_OK) return rc;
     rc = ensure_bounce(ctx, bneed);
@@ -1143,6 +1162,21 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
     } sync_guard{ctx};
     HIP_TRY(ctx, hipMemcpyAsync(d + o_pt, pt, n * 16, hipMemcpyHostToDevice, ctx->s_compute));
     if (keys) HIP_TRY(ctx, hipMemcpyAsync(d + o_keys, keys, pbk ? n * 16 : 16, hipMemcpyHostToDevice, ctx->s_compute));
+    auto slab_of = [&](int s) { return aesw_key_slab{d + ks_off[s][0], d + ks_off[s][1], d + ks_off[s][2], d + ks_off[s][3]}; };
+    const uint8_t *d_key16 = nullptr;  // the 16 key bytes of a shared / scheduled key on the device (the literal rows of words_column)
+    if (checking && !pbk) {
+        // a scheduled key's bytes are the first round key of its slot (rk[0] = the key, src/key_schedule.rs:107-114)
+        d_key16 = keys ? d + o_keys : ctx->key_slots[ctx->key_cur].d;
+        if (!keys) {
+            aesw_ctx::KeySlot &sl = ctx->key_slots[ctx->key_cur];
+            if (!sl.pinned && sl.writer != ctx->s_compute) HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_compute, sl.ready, 0));
+        }
+        const aesw_key_slab one = slab_of(0);
+        KeyParams kp{d_key16, ctx->d_tables, KeyOut{one.w, one.kx, one.ky, one.kz}, nullptr, 1, 0, 0};
+        HIP_TRY(ctx, launch_key(kp, layout, ctx->xt, 1, ctx->key_nt, 0u, ctx->s_compute));
+        if (!keys) { const int r = key_track_reader(ctx, ctx->key_slots[ctx->key_cur], ctx->s_compute); if (r != AESW_OK) return r; }
+    }
+    uint64_t chunk_index = 0;
     // per stage: kernel start / end, copy start / end (timed: aesw_last_stream_stats reports where the time went)
     hipEvent_t started[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, copy0[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
     struct EvGuard {
@@ -1161,9 +1195,19 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
     bool busy[2] = {false, false};
     auto issue = [&](int s, uint64_t b0, uint64_t m) -> int {
         HIP_TRY(ctx, hipEventRecord(started[s], ctx->s_compute));
+        const aesw_key_slab stage_slab = slab_of(s);
         int r = aesw_encrypt_witness_device(ctx, d + o_pt + 16 * b0, !keys ? nullptr : (pbk ? d + o_keys + 16 * b0 : d + o_keys), per_block_keys, m,
-                                            layout, d + col_off[s][0], d + col_off[s][1], d + col_off[s][2], nullptr, nullptr, ctx->s_compute);
+                                            layout, d + col_off[s][0], d + col_off[s][1], d + col_off[s][2], nullptr,
+                                            checking && pbk ? &stage_slab : nullptr, ctx->s_compute);
         if (r != AESW_OK) return r;
+        if (checking) {
+            r = check_witness_impl(ctx, d + o_pt + 16 * b0, pbk ? d + o_keys + 16 * b0 : d_key16, per_block_keys, m, layout, d + col_off[s][0],
+                                   d + col_off[s][1], d + col_off[s][2], nullptr, &stage_slab,
+                                   reinterpret_cast<aesw_check_report *>(d + o_rep) + chunk_index, ctx->s_compute, !pbk && chunk_index != 0);
+            if (r != AESW_OK) return r;
+            if (!keys) { r = key_track_reader(ctx, ctx->key_slots[ctx->key_cur], ctx->s_compute); if (r != AESW_OK) return r; }
+            ++chunk_index;
+        }
         HIP_TRY(ctx, hipEventRecord(done[s], ctx->s_compute));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_copy, done[s], 0));
         HIP_TRY(ctx, hipEventRecord(copy0[s], ctx->s_copy));
@@ -1209,6 +1253,29 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
     }
     st.wall_ns = now_ns() - t_begin;
     ctx->stats = st;
+    if (checking) {  // every chunk's kernel and check have finished (their columns have been copied): sum the reports
+        std::vector<aesw_check_report> reps((size_t)n_chunks);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->s_compute));  // (a non-blocking stream: the copy below does not wait for it by itself)
+        HIP_TRY(ctx, hipMemcpy(reps.data(), d + o_rep, reps.size() * sizeof(aesw_check_report), hipMemcpyDeviceToHost));
+        aesw_check_report &t = ctx->stream_report;
+        for (uint64_t i = 0; i < n_chunks; ++i) {
+            const aesw_check_report &r = reps[i];
+            t.blocks += r.blocks; t.keys += r.keys;
+            t.lookup_failures += r.lookup_failures; t.copy_failures += r.copy_failures;
+            t.gate_failures += r.gate_failures; t.input_failures += r.input_failures;
+            if (r.first != AESW_CHECK_NONE) {
+                const uint64_t unit = (r.first >> 20) + ((!pbk && ((r.first >> 19) & 1)) ? 0 : i * chunk);
+                const uint64_t f = unit << 20 | (r.first & 0xfffffu);
+                if (f < t.first) t.first = f;
+            }
+        }
+    }
+    return AESW_OK;
+}
+
+int aesw_last_stream_check(const aesw_ctx *ctx, aesw_check_report *out) {
+    if (!ctx || !out) return AESW_ERR_INVALID_ARG;
+    *out = ctx->stream_report;
     return AESW_OK;
 }
 

@@ -101,6 +101,8 @@ struct aesw_ctx {
     uint8_t *scratch = nullptr;  // device buffers of the host-pointer path (grow-only)
     size_t scratch_bytes = 0;
     aesw_stream_stats stats = {};  // of the last streaming call
+    int stream_check = 0;          // option: aesw_encrypt_witness_stream checks every chunk on the device before it travels (aesw_check.h)
+    aesw_check_report stream_report = {0, 0, 0, 0, 0, 0, ~0ull};  // of the last streaming call with "stream_check" on
 };
 
 inline int fail_hip(aesw_ctx *ctx, hipError_t e, const char *what) {

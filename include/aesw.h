@@ -406,6 +406,12 @@ int aesw_host_register(void *p, size_t bytes);
 int aesw_host_unregister(void *p);
 int aesw_key_schedule_witness(aesw_ctx *ctx, const uint8_t *keys, uint64_t n, int layout,
                               uint8_t *w, uint8_t *kx, uint8_t *ky, uint8_t *kz, uint8_t *rk);
+/* With option "stream_check" = 1, aesw_encrypt_witness_stream runs aesw_check_witness_device over every chunk on the device -- behind
+ * the kernel that produced it, while the previous chunk travels to the host -- so the whole stream is certified against the
+ * reference's constraints without the consumer doing anything (BASELINE configs[4]; DENSE and PACKED layouts; ~70 us per 2^15-block
+ * chunk, hidden under its 1.8 ms of D2H).  The sum over the chunks, with batch-wide unit numbers in `first`, is read back here after
+ * the stream call has returned (blocks = 0 when the option was off or the layout was VALUES). */
+int aesw_last_stream_check(const aesw_ctx *ctx, aesw_check_report *out);
 /* host-pointer aesw_check_witness_device: every pointer is a host buffer, *report is written on the host when the call returns.
  * The batch is uploaded and checked in stages of "chunk_blocks" blocks; units in report->first are batch-wide indices. */
 int aesw_check_witness(aesw_ctx *ctx, const uint8_t *pt, const uint8_t *keys, int per_block_keys, uint64_t n,
@@ -456,7 +462,8 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * the block groups per XCD (default), C >= 2 = the XCDs take turns in chunks of C groups), "force_table_path" (1), "chunk_blocks" (blocks per stage of the host-pointer
  * pipeline, default 2^15), "batch_streams" (internal streams of aesw_encrypt_witness_batches_device, 1 ... 8, default 3), "split_small" (0 = off: the default; 2 ... 8: a LONE shared- or
  * scheduled-key batch of 2^15 ... 2^17 blocks is dealt as that many sub-ranges of whole 48-block groups onto the internal streams -- an
- * experiment of round 4 that measured 4 - 8 us SLOWER at every size, profiles/r04_study/split_small.md), "key_slots" (round-key slots
+ * experiment of round 4 that measured 4 - 8 us SLOWER at every size, profiles/r04_study/split_small.md), "stream_check" (0 / 1: check every chunk of aesw_encrypt_witness_stream on the
+ * device, result through aesw_last_stream_check; default 0), "key_slots" (round-key slots
  * aesw_schedule_key* cycles through, 1 ... 64, default 4; with 1 every schedule waits for all launches reading the previous key), "copy_threads" (host threads that move a stage from the page-locked bounce buffer into a PAGEABLE destination;
  * -1 = auto: a quarter of the CPUs the process may run on, 1 ... 4; page-locked destinations receive the DMA directly and use none), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB

@@ -283,6 +283,7 @@ extern "C" {
         d_report: *mut aesw_check_report,
         stream: *mut c_void,
     ) -> c_int;
+    pub fn aesw_last_stream_check(ctx: *const aesw_ctx, out: *mut aesw_check_report) -> c_int;
     pub fn aesw_check_witness(
         ctx: *mut aesw_ctx,
         pt: *const u8,

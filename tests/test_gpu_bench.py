@@ -49,6 +49,8 @@ def test_bench_single_gpu_line(pkg):
     for lay in ("packed", "values"):
         c4 = ex["c4"][lay]
         assert c4["mismatches"] == 0 and c4["sampled_chunks_verified_after_the_stream"] >= 1 and c4["blocks"] == 1 << 17
+        sc = c4["stream_check"]  # packed: every block of the stream checked on the device on its way out; values-only: not checkable
+        assert sc["satisfied"] and sc["blocks"] == ((1 << 17) if lay == "packed" else 0)
 
 
 def test_bench_two_ranks_on_one_gpu_rehearses_the_multi_gpu_tail(pkg):

@@ -815,3 +815,50 @@ def test_gather_moves_the_right_bytes_between_five_processes(pkg, tmp_path):
         assert procs[0].returncode != 0 and "cut the range differently" in outs[0], outs
     finally:
         shutil.rmtree(box, ignore_errors=True)
+
+
+@pytest.mark.parametrize("mode", ["scheduled", "shared", "per_block"])
+def test_stream_check_certifies_every_chunk(pkg, oracle, mode):
+    """Option "stream_check" (BASELINE configs[4]: the stream to the host, now certified on the way): every chunk of
+    aesw_encrypt_witness_stream is checked on the device behind its kernel; aesw_last_stream_check sums the chunks.  Several
+    chunks with a ragged last one, the three key modes, PACKED and DENSE: the consumer still receives the oracle's bytes, the report
+    counts every block (and key slab) exactly once and is satisfied; VALUES streams are not checked; off by default."""
+    c = pkg.Context(0)
+    c.set_option("chunk_blocks", 2048)
+    rng = np.random.default_rng(40)
+    n = 4 * 2048 + 333
+    pt = rng.integers(0, 256, (n, 16), dtype=np.uint8)
+    keys = rng.integers(0, 256, (n, 16) if mode == "per_block" else 16, dtype=np.uint8)
+    if mode == "scheduled":
+        import torch
+        c.schedule_key(torch.from_numpy(keys).cuda(), key_slab=False)
+        torch.cuda.synchronize()
+    arg_keys = None if mode == "scheduled" else keys
+    got = {}
+
+    def consume(first, count, x, y, z):
+        got[first] = (count, x.copy(), y.copy(), z.copy())
+        return 0
+
+    c.encrypt_witness_stream(pt, arg_keys, consume, layout=pkg.LAYOUT_PACKED)
+    assert c.last_stream_check()["blocks"] == 0  # the option is off by default
+    c.set_option("stream_check", 1)
+    for layout, olay in ((pkg.LAYOUT_PACKED, ol.PACKED), (pkg.LAYOUT_DENSE, ol.DENSE)):
+        got.clear()
+        c.encrypt_witness_stream(pt, arg_keys, consume, layout=layout)
+        rep = c.last_stream_check()
+        assert rep["satisfied"] and rep["first"] is None and rep["blocks"] == n and rep["keys"] == (n if mode == "per_block" else 1), (layout, rep)
+        e = oracle.encrypt_witness(pt, keys, layout=olay, threads=THREADS)
+        sx, sy, sz = (pkg.column_stride(layout, i) for i in range(3))
+        assert sorted(got) == list(range(0, n, 2048))
+        for first, (count, x, y, z) in got.items():
+            assert np.array_equal(x, e.x[first * sx:(first + count) * sx]) and np.array_equal(y, e.y[first * sy:(first + count) * sy])
+            assert np.array_equal(z, e.z[first * sz:(first + count) * sz])
+    c.encrypt_witness_stream(pt, arg_keys, lambda *a: 0, layout=pkg.LAYOUT_VALUES)
+    assert c.last_stream_check()["blocks"] == 0
+    # a context whose tables differ from the ones the circuit is checked with cannot happen (they are one and the same), so provoke a
+    # failure the other way: a force_table_path context is still satisfied (another kernel path, same constraints)
+    c.set_option("force_table_path", 1)
+    c.encrypt_witness_stream(pt, arg_keys, lambda *a: 0, layout=pkg.LAYOUT_PACKED)
+    assert c.last_stream_check()["satisfied"] and c.last_stream_check()["blocks"] == n
+    c.close()

@@ -295,6 +295,21 @@ int main(void) {
                 free(hw); free(hkx); free(hky); free(hkz);
             }
         }
+        {   /* round 4: "stream_check": the stream entry point with a device check per chunk, scheduled key and per-block keys */
+            aesw_check_report sr;
+            uint64_t nchunks = 0;
+            CHECK(aesw_set_option(ctx, "stream_check", 1));
+            CHECK(aesw_set_option(ctx, "chunk_blocks", 20000));
+            CHECK(aesw_schedule_key(ctx, hk, AESW_LAYOUT_PACKED, NULL));
+            CHECK(aesw_encrypt_witness_stream(ctx, hp, NULL, 0, na, AESW_LAYOUT_PACKED, consume, &nchunks));
+            CHECK(aesw_last_stream_check(ctx, &sr));
+            if (sr.blocks != na || sr.keys != 1 || sr.first != AESW_CHECK_NONE) { fprintf(stderr, "stream_check (scheduled key): %llu blocks\n", (unsigned long long)sr.blocks); return 1; }
+            CHECK(aesw_encrypt_witness_stream(ctx, hp, hk, 1, na, AESW_LAYOUT_DENSE, consume, &nchunks));
+            CHECK(aesw_last_stream_check(ctx, &sr));
+            if (sr.blocks != na || sr.keys != na || sr.first != AESW_CHECK_NONE) { fprintf(stderr, "stream_check (per-block keys, dense)\n"); return 1; }
+            CHECK(aesw_set_option(ctx, "stream_check", 0));
+            CHECK(aesw_set_option(ctx, "chunk_blocks", 1 << 15));
+        }
         {   /* round 4: the scheduled key's slot ring.  Twenty reader streams (more than a slot tracks: folding), re-schedules
              * on rings of 1, 2 and 4 slots, a lone launch dealt out by "split_small"; the last key's output is checked */
             hipStream_t st[20];
