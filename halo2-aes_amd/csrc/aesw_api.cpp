@@ -480,6 +480,7 @@ int aesw_set_option(aesw_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "key_slots")) { if (value < 1 || value > 64) return AESW_ERR_INVALID_ARG; ctx->key_ring = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "split_small")) { if (value < 0 || value > 8) return AESW_ERR_INVALID_ARG; ctx->split_small = (int)value; return AESW_OK; }
     if (!std::strcmp(name, "stream_check")) { if (value != 0 && value != 1) return AESW_ERR_INVALID_ARG; ctx->stream_check = (int)value; return AESW_OK; }
+    if (!std::strcmp(name, "stream_poison")) { if (value < 0) return AESW_ERR_INVALID_ARG; ctx->stream_poison = value; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache")) {  // 0 also releases what is cached now
         if (value != 0 && value != 1) return AESW_ERR_INVALID_ARG;
         ctx->arena_cache_on = (int)value;
@@ -563,6 +564,7 @@ int aesw_get_option(const aesw_ctx *ctx, const char *name, int64_t *value) {
     if (!std::strcmp(name, "key_slots")) { *value = ctx->key_ring; return AESW_OK; }
     if (!std::strcmp(name, "split_small")) { *value = ctx->split_small; return AESW_OK; }
     if (!std::strcmp(name, "stream_check")) { *value = ctx->stream_check; return AESW_OK; }
+    if (!std::strcmp(name, "stream_poison")) { *value = ctx->stream_poison; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache")) { *value = ctx->arena_cache_on; return AESW_OK; }
     if (!std::strcmp(name, "arena_cache_max_mb")) { *value = (int64_t)(ctx->arena_cache_max_bytes >> 20); return AESW_OK; }
     if (!std::strcmp(name, "arena_probe_budget_ms")) { *value = ctx->arena_probe_budget_ms; return AESW_OK; }
@@ -1200,6 +1202,13 @@ int aesw_encrypt_witness_stream(aesw_ctx *ctx, const uint8_t *pt, const uint8_t 
                                             layout, d + col_off[s][0], d + col_off[s][1], d + col_off[s][2], nullptr,
                                             checking && pbk ? &stage_slab : nullptr, ctx->s_compute);
         if (r != AESW_OK) return r;
+        if (ctx->stream_poison > 0 && (uint64_t)ctx->stream_poison - 1 >= b0 && (uint64_t)ctx->stream_poison - 1 < b0 + m) {
+            // diagnostic: two cells of one block are overwritten between the kernel and the check (tests/test_gpu_round4.py shows the
+            // stream check names that block, by its batch-wide index, in whatever chunk it lies)
+            const uint64_t pb = (uint64_t)ctx->stream_poison - 1 - b0;
+            HIP_TRY(ctx, hipMemsetAsync(d + col_off[s][1] + pb * strides[1] + 5, 0x5A, 1, ctx->s_compute));
+            HIP_TRY(ctx, hipMemsetAsync(d + col_off[s][2] + pb * strides[2] + 7, 0xA5, 1, ctx->s_compute));
+        }
         if (checking) {
             r = check_witness_impl(ctx, d + o_pt + 16 * b0, pbk ? d + o_keys + 16 * b0 : d_key16, per_block_keys, m, layout, d + col_off[s][0],
                                    d + col_off[s][1], d + col_off[s][2], nullptr, &stage_slab,

@@ -102,6 +102,7 @@ struct aesw_ctx {
     size_t scratch_bytes = 0;
     aesw_stream_stats stats = {};  // of the last streaming call
     int stream_check = 0;          // option: aesw_encrypt_witness_stream checks every chunk on the device before it travels (aesw_check.h)
+    int64_t stream_poison = 0;     // diagnostic (tests): block index + 1 whose y / z cells the stream overwrites before its chunk is checked and shipped
     aesw_check_report stream_report = {0, 0, 0, 0, 0, 0, ~0ull};  // of the last streaming call with "stream_check" on
 };
 

@@ -463,7 +463,8 @@ int aesw_gather_columns_device(aesw_comm *comm, int root, int n_cols, const uint
  * pipeline, default 2^15), "batch_streams" (internal streams of aesw_encrypt_witness_batches_device, 1 ... 8, default 3), "split_small" (0 = off: the default; 2 ... 8: a LONE shared- or
  * scheduled-key batch of 2^15 ... 2^17 blocks is dealt as that many sub-ranges of whole 48-block groups onto the internal streams -- an
  * experiment of round 4 that measured 4 - 8 us SLOWER at every size, profiles/r04_study/split_small.md), "stream_check" (0 / 1: check every chunk of aesw_encrypt_witness_stream on the
- * device, result through aesw_last_stream_check; default 0), "key_slots" (round-key slots
+ * device, result through aesw_last_stream_check; default 0), "stream_poison" (diagnostic for the tests: block index + 1 whose y / z cells the
+ * stream overwrites between kernel and check; 0 = off), "key_slots" (round-key slots
  * aesw_schedule_key* cycles through, 1 ... 64, default 4; with 1 every schedule waits for all launches reading the previous key), "copy_threads" (host threads that move a stage from the page-locked bounce buffer into a PAGEABLE destination;
  * -1 = auto: a quarter of the CPUs the process may run on, 1 ... 4; page-locked destinations receive the DMA directly and use none), "lds_pad" (diagnostic: extra LDS bytes per workgroup, lowers residency), "fr_store_mode" / "key_store_mode" (store
  * flavour of the Fr-expanding kernels and of the key-schedule kernel, default 1), "fr_geometry" (0 striding workgroups, 1 one-shot 4 KiB

@@ -856,6 +856,15 @@ def test_stream_check_certifies_every_chunk(pkg, oracle, mode):
             assert np.array_equal(z, e.z[first * sz:(first + count) * sz])
     c.encrypt_witness_stream(pt, arg_keys, lambda *a: 0, layout=pkg.LAYOUT_VALUES)
     assert c.last_stream_check()["blocks"] == 0
+    # the check sees what travels: two cells of one block overwritten between kernel and check ("stream_poison", diagnostic) are
+    # reported with the block's BATCH-WIDE index, whichever chunk it lies in -- the first, a middle one, the ragged last one
+    for victim in (7, 2 * 2048 + 100, n - 1):
+        c.set_option("stream_poison", victim + 1)
+        c.encrypt_witness_stream(pt, arg_keys, lambda *a: 0, layout=pkg.LAYOUT_PACKED)
+        rep = c.last_stream_check()
+        assert not rep["satisfied"] and rep["blocks"] == n and rep["first"][0] == victim and not rep["first"][1], (victim, rep)
+        assert 1 <= rep["lookup_failures"] <= 3 and rep["copy_failures"] >= 1
+    c.set_option("stream_poison", 0)
     # a context whose tables differ from the ones the circuit is checked with cannot happen (they are one and the same), so provoke a
     # failure the other way: a force_table_path context is still satisfied (another kernel path, same constraints)
     c.set_option("force_table_path", 1)
