@@ -38,6 +38,13 @@ def main(n=3000, k=20, n_sets=4):
     torch.cuda.synchronize()
     print("1. witness of %d blocks on the device: %.2f ms (includes the first-launch set-up)" % (n, (time.perf_counter() - t0) * 1e3))
 
+    # 1b. the reference's own correctness test -- MockProver's constraint satisfaction -- on the device, before any circuit is built
+    t0 = time.perf_counter()
+    rep = ctx.check_witness(torch.from_numpy(pts).cuda(), torch.from_numpy(key).cuda(), wit, key_witness, ct=wit.ct)
+    assert rep["satisfied"] and rep["blocks"] == n and rep["keys"] == 1, rep
+    print("1b. every lookup, copy constraint, gate and literal row of %d blocks + the key slab checked on the device: %.2f ms" % (
+        n, (time.perf_counter() - t0) * 1e3))
+
     # 2. synthesize() + MockProver on the full witness
     t0 = time.perf_counter()
     with pkg.HostCircuit.aes(ctx, k, n_sets, key, pts) as mock:
