@@ -992,7 +992,17 @@ def main():
                     dev4 = "cuda" if a.backend == "nccl" else "cpu"
                     tmax = torch.tensor([t_rank, r4["kernel_s"], r4["d2h_s"], r4["consumer_s"], r4["wait_s"]], dtype=torch.float64, device=dev4)
                     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                    tsum = torch.tensor([float(r4["mismatches"]), r4["d2h_GBps"]], dtype=torch.float64, device=dev4)
+                    chk4 = {"blocks": 0, "satisfied": True}
+                    if lay != pkg.LAYOUT_VALUES:
+                        # untimed: the same shard streamed once more with "stream_check": every block certified on the device on its way out
+                        ctx.set_option("stream_check", 1)
+                        try:
+                            ctx.encrypt_witness_stream(pt4, None, lambda *args: 0, layout=lay)
+                            chk4 = ctx.last_stream_check()
+                        finally:
+                            ctx.set_option("stream_check", 0)
+                    bad4 = r4["mismatches"] + (0 if (chk4["satisfied"] and chk4["blocks"] in (0, n4)) else 1)
+                    tsum = torch.tensor([float(bad4), r4["d2h_GBps"], float(chk4["blocks"])], dtype=torch.float64, device=dev4)
                     dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
                     per = sum(pkg.column_stride(lay, c) for c in range(3))
                     c4n[name] = {"blocks_per_rank": n4, "blocks_total": n4 * world, "seconds_max_over_ranks": float(tmax[0]),
@@ -1000,7 +1010,7 @@ def main():
                                  "GBps_to_hosts_all_ranks": n4 * world * per / float(tmax[0]) / 1e9,
                                  "d2h_GBps_per_rank_mean": float(tsum[1]) / world,
                                  "kernel_s_max": float(tmax[1]), "d2h_s_max": float(tmax[2]), "consumer_s_max": float(tmax[3]),
-                                 "wait_s_max": float(tmax[4]), "mismatches": int(tsum[0]),
+                                 "wait_s_max": float(tmax[4]), "mismatches": int(tsum[0]), "stream_check_blocks_all_ranks": int(tsum[2]),
                                  "rank0": {k: r4[k] for k in ("seconds", "kernel_s", "d2h_s", "d2h_GBps", "consumer_s", "wait_s", "chunks")}}
                 dog.disarm()
                 if rank == 0:

@@ -68,4 +68,5 @@ def test_bench_two_ranks_on_one_gpu_rehearses_the_multi_gpu_tail(pkg):
     assert "error" not in c4
     for lay in ("packed", "values"):
         assert c4[lay]["blocks_total"] == 2 << 17 and c4[lay]["mismatches"] == 0 and c4[lay]["blocks_per_s_to_hosts"] > 0
+        assert c4[lay]["stream_check_blocks_all_ranks"] == ((2 << 17) if lay == "packed" else 0)  # every rank's shard certified on the device
         assert c4[lay]["seconds_max_over_ranks"] >= c4[lay]["rank0"]["seconds"] * 0.5
